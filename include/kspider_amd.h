@@ -1,0 +1,109 @@
+/* kspider_amd — C ABI of the MI355X-native pairwise containment engine.
+ *
+ * This is the drop-in boundary for ONE path of dib-lab/kSpider: kSpider::pairwise()
+ * (reference: include/kSpider.hpp:11, src/pairwise.cpp:123-276, SWIG wrapper
+ * src/swig_interfaces/kSpider_internal.i:11).  Plain pointers and sizes only; no
+ * torch / C++ types.  Every function returns 0 on success, a KSP_E_* code otherwise;
+ * ksp_last_error() gives the message of the calling thread's last failure.
+ *
+ * There is NO CPU fallback behind these entry points: without a visible gfx950
+ * device (or without the HIP runtime) they fail with KSP_E_HIP.
+ */
+#ifndef KSPIDER_AMD_H
+#define KSPIDER_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    KSP_OK = 0,
+    KSP_E_ARG = 1,      /* bad argument */
+    KSP_E_HIP = 2,      /* HIP runtime / device failure */
+    KSP_E_IO = 3,       /* missing / malformed index file */
+    KSP_E_OVERFLOW = 4, /* edge buffer too small: *count holds the required size */
+    KSP_E_LIMIT = 5     /* input exceeds an engine limit */
+};
+
+/* One row of the reference's PAIRS_COUNTER (src/pairwise.cpp:22-27):
+ * key pair<uint32,uint32> with source_1 < source_2, value uint64 shared k-mers. */
+typedef struct ksp_edge {
+    uint32_t source_1;
+    uint32_t source_2;
+    uint64_t shared;
+} ksp_edge;
+
+typedef struct ksp_engine ksp_engine;
+
+typedef struct ksp_stats {
+    uint64_t n_sources;
+    uint64_t n_entries;     /* sum of sketch sizes                                  */
+    uint64_t n_blocks;      /* ceil(n_sources / 128)                                */
+    uint64_t n_block_keys;  /* distinct keys summed over blocks                     */
+    uint64_t n_tiles;       /* n_blocks (n_blocks + 1) / 2                          */
+    uint64_t last_tiles;    /* tiles joined by the last ksp_engine_join             */
+    uint64_t last_pairs;    /* source pairs covered by the last ksp_engine_join     */
+    uint64_t last_stream_bytes; /* bytes the join kernel streamed (model) */
+    uint64_t last_edges;    /* non-zero pairs found by the last join                */
+    float ms_build;         /* HIP-event time of the last build_blocks (all kernels) */
+    float ms_join;          /* HIP-event time of the last join kernel launch        */
+    int weighted;
+    int key_bits;
+} ksp_stats;
+
+const char* ksp_last_error(void);
+int ksp_device_count(int* count);
+
+/* ---- the hot path on device-resident data ------------------------------------------
+ * Replaces the accumulate region of the reference, src/pairwise.cpp:194-237
+ * (Combo::combinations + PAIRS_COUNTER::try_emplace_l), for sketches laid out as sorted
+ * uint64 runs in HBM.  Source ids in the edges are dense indices 0..n_sources-1.      */
+int ksp_engine_create(int device, ksp_engine** out);
+void ksp_engine_destroy(ksp_engine* e);
+
+/* Stage 1: merge the sorted runs of every block of 128 sources into one sorted
+ * posting list per block (device).  d_keys: device pointer, concatenated sorted-unique
+ * uint64 runs; d_weights: device pointer (one uint32 per key entry; the colour weight
+ * w_c of src/pairwise.cpp:221) or NULL for weight 1; h_offsets: HOST pointer,
+ * n_sources+1 element offsets; key_bits: significant bits of the largest key, 0 = find
+ * out on the device.  stream: hipStream_t (NULL = default stream).                    */
+int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights,
+                            const uint64_t* h_offsets, uint32_t n_sources, int key_bits, void* stream);
+
+/* Tiles of the block-pair upper triangle in row-major order: tile t <-> (I, J), I <= J. */
+uint64_t ksp_engine_num_tiles(const ksp_engine* e);
+/* Source pairs covered by tiles [tile_begin, tile_end): the worst-case edge count.     */
+uint64_t ksp_engine_tile_pairs(const ksp_engine* e, uint64_t tile_begin, uint64_t tile_end);
+
+/* Stage 2: join tiles [tile_begin, tile_end) and append every pair with shared > 0 to
+ * d_edges (device buffer of `capacity` edges; order unspecified).  *h_count receives the
+ * number of non-zero pairs; if it exceeds capacity the surplus was dropped and the call
+ * returns KSP_E_OVERFLOW.  Synchronises `stream` before returning.                      */
+int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_edge* d_edges, uint64_t capacity,
+                    uint64_t* h_count, void* stream);
+
+int ksp_engine_get_stats(const ksp_engine* e, ksp_stats* out);
+
+/* ---- thin device-memory helpers so that FFI callers need no HIP binding ------------- */
+int ksp_device_malloc(int device, uint64_t bytes, void** d_ptr);
+int ksp_device_free(void* d_ptr);
+int ksp_memcpy_h2d(void* d_dst, const void* h_src, uint64_t bytes);
+int ksp_memcpy_d2h(void* h_dst, const void* d_src, uint64_t bytes);
+
+/* ---- host-buffer convenience (H2D + both stages + D2H), edges sorted by (s1, s2) ---- */
+int ksp_pairwise_host(const uint64_t* keys, const uint32_t* weights, const uint64_t* offsets, uint32_t n_sources,
+                      int device, ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats);
+void ksp_free(void* p);
+
+/* ---- the reference entry point ------------------------------------------------------
+ * Same contract as kSpider::pairwise(string index_prefix, int user_threads)
+ * (include/kSpider.hpp:11): reads PREFIX_color_to_sources.bin, PREFIX_color_count.bin,
+ * PREFIX_groupID_to_kmerCount.bin, writes PREFIX_kSpider_seqToKmersNo.tsv and
+ * PREFIX_kSpider_pairwise.tsv.  Device = $KSPIDER_DEVICE (default 0).                  */
+int kspider_pairwise(const char* index_prefix, int user_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KSPIDER_AMD_H */

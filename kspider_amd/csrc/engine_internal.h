@@ -1,0 +1,18 @@
+// Internal declarations shared by the engine (engine.hip) and the host-side
+// reference surface (pairwise_host.cpp).  Not part of the C ABI.
+#ifndef KSPIDER_ENGINE_INTERNAL_H
+#define KSPIDER_ENGINE_INTERNAL_H
+#include <cstdint>
+#include <string>
+
+#include "../../include/kspider_amd.h"
+
+namespace ksp {
+void set_error(const std::string& s);
+}
+
+extern "C" {
+/* test/diagnostic hook: distinct-key offsets of the block lists (nb + 1 values). */
+int ksp_engine_block_key_counts(const ksp_engine* e, uint32_t* h_blk_off);
+}
+#endif

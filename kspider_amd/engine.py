@@ -1,0 +1,192 @@
+"""ctypes binding of the C ABI in ``include/kspider_amd.h``.
+
+Everything here goes through ``libkspider_amd.so`` (hand-written HIP for gfx950).
+There is no CPU fallback: if the library is missing or no MI355X is visible the
+calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkspider_amd.so")
+
+EDGE_DTYPE = np.dtype([("source_1", "<u4"), ("source_2", "<u4"), ("shared", "<u8")])
+
+KSP_OK, KSP_E_ARG, KSP_E_HIP, KSP_E_IO, KSP_E_OVERFLOW, KSP_E_LIMIT = range(6)
+
+#: every symbol include/kspider_amd.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "ksp_last_error", "ksp_device_count", "ksp_engine_create", "ksp_engine_destroy",
+    "ksp_engine_build_blocks", "ksp_engine_num_tiles", "ksp_engine_tile_pairs", "ksp_engine_join",
+    "ksp_engine_get_stats", "ksp_device_malloc", "ksp_device_free", "ksp_memcpy_h2d", "ksp_memcpy_d2h",
+    "ksp_pairwise_host", "ksp_free", "kspider_pairwise",
+]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("n_sources", ctypes.c_uint64), ("n_entries", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64),
+        ("n_block_keys", ctypes.c_uint64), ("n_tiles", ctypes.c_uint64), ("last_tiles", ctypes.c_uint64),
+        ("last_pairs", ctypes.c_uint64), ("last_stream_bytes", ctypes.c_uint64), ("last_edges", ctypes.c_uint64),
+        ("ms_build", ctypes.c_float), ("ms_join", ctypes.c_float), ("weighted", ctypes.c_int),
+        ("key_bits", ctypes.c_int),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class KspError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"kspider_amd error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libkspider_amd.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(the HIP extension is mandatory, there is no CPU fallback)")
+        L = ctypes.CDLL(LIB_PATH)
+        L.ksp_last_error.restype = ctypes.c_char_p
+        L.ksp_engine_num_tiles.restype = ctypes.c_uint64
+        L.ksp_engine_num_tiles.argtypes = [ctypes.c_void_p]
+        L.ksp_engine_tile_pairs.restype = ctypes.c_uint64
+        L.ksp_engine_tile_pairs.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
+        L.ksp_engine_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.ksp_engine_destroy.argtypes = [ctypes.c_void_p]
+        L.ksp_engine_destroy.restype = None
+        L.ksp_engine_build_blocks.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+        L.ksp_engine_join.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
+                                      ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]
+        L.ksp_engine_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
+        L.ksp_device_malloc.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+        L.ksp_device_free.argtypes = [ctypes.c_void_p]
+        L.ksp_memcpy_h2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        L.ksp_memcpy_d2h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        L.ksp_pairwise_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                        ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                        ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(Stats)]
+        L.ksp_free.argtypes = [ctypes.c_void_p]
+        L.ksp_free.restype = None
+        if hasattr(L, 'kspider_pairwise'):  # TEMP until pairwise_host.cpp lands
+            L.kspider_pairwise.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != KSP_OK:
+        raise KspError(rc, lib().ksp_last_error().decode(errors="replace"))
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    _check(lib().ksp_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def pairwise_host(keys: np.ndarray, offsets: np.ndarray, weights: np.ndarray | None = None, device: int = 0):
+    """Host sketches -> (edges sorted by (source_1, source_2), stats).  IDs are dense 0..N-1."""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    w = None if weights is None else np.ascontiguousarray(weights, dtype=np.uint32)
+    n = offsets.size - 1
+    out = ctypes.c_void_p()
+    ne = ctypes.c_uint64(0)
+    st = Stats()
+    _check(lib().ksp_pairwise_host(keys.ctypes.data, w.ctypes.data if w is not None else None, offsets.ctypes.data,
+                                   n, device, ctypes.byref(out), ctypes.byref(ne), ctypes.byref(st)))
+    try:
+        buf = (ctypes.c_char * (ne.value * EDGE_DTYPE.itemsize)).from_address(out.value) if ne.value else b""
+        edges = np.frombuffer(buf, dtype=EDGE_DTYPE).copy()
+    finally:
+        lib().ksp_free(out)
+    return edges, st.as_dict()
+
+
+class Engine:
+    """Device-resident engine: build_blocks() once per sketch set, join() per tile range."""
+
+    def __init__(self, device: int = 0):
+        self.device = device
+        self._h = ctypes.c_void_p()
+        _check(lib().ksp_engine_create(device, ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().ksp_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def build_blocks(self, d_keys_ptr: int, h_offsets: np.ndarray, d_weights_ptr: int = 0, key_bits: int = 0,
+                     stream: int = 0):
+        h_offsets = np.ascontiguousarray(h_offsets, dtype=np.uint64)
+        self._off = h_offsets
+        _check(lib().ksp_engine_build_blocks(self._h, d_keys_ptr or None, d_weights_ptr or None,
+                                             h_offsets.ctypes.data, h_offsets.size - 1, key_bits, stream or None))
+
+    @property
+    def num_tiles(self) -> int:
+        return lib().ksp_engine_num_tiles(self._h)
+
+    def tile_pairs(self, t0: int, t1: int) -> int:
+        return lib().ksp_engine_tile_pairs(self._h, t0, t1)
+
+    def join(self, t0: int, t1: int, d_edges_ptr: int, capacity: int, stream: int = 0) -> int:
+        cnt = ctypes.c_uint64(0)
+        _check(lib().ksp_engine_join(self._h, t0, t1, d_edges_ptr or None, capacity, ctypes.byref(cnt),
+                                     stream or None))
+        return cnt.value
+
+    def stats(self) -> dict:
+        st = Stats()
+        _check(lib().ksp_engine_get_stats(self._h, ctypes.byref(st)))
+        return st.as_dict()
+
+
+class DeviceBuffer:
+    """hipMalloc'ed buffer through the C ABI (tests use it instead of torch)."""
+
+    def __init__(self, nbytes: int, device: int = 0):
+        self.ptr = ctypes.c_void_p()
+        self.nbytes = int(nbytes)
+        _check(lib().ksp_device_malloc(device, self.nbytes, ctypes.byref(self.ptr)))
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray, device: int = 0):
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes, device)
+        _check(lib().ksp_memcpy_h2d(b.ptr, a.ctypes.data, a.nbytes))
+        return b
+
+    def to_numpy(self, dtype, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        _check(lib().ksp_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().ksp_device_free(self.ptr)
+            self.ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
