@@ -6,10 +6,12 @@
 // (PAIRS_COUNTER, :22-27).  Here the per-source hash sets live in HBM as sorted
 // uint64 runs and the N x N shared-k-mer matrix is produced tile by tile:
 //
-//   stage 1 (build_blocks)  the sorted runs of each block of TB = 128 sources are
-//            merged into ONE sorted list of distinct keys with postings (which of
-//            the 128 sources hold the key) — so a key is compared once per block
-//            pair instead of once per source pair (128x fewer comparisons).
+//   stage 1 (build_blocks)  every 64-bit hash is replaced by its dense rank among all
+//            distinct hashes (exact, order preserving, 32 bit), and the sorted runs of
+//            each block of TB = 128 sources are merged into ONE sorted list of
+//            distinct ranks with postings (which of the 128 sources hold the key) —
+//            so a key is compared once per block pair instead of once per source
+//            pair (128x fewer comparisons, half the bytes).
 //   stage 2 (k_join)        one workgroup per block pair (I, J): a 128 x 128 tile of
 //            uint32 pair counters lives in LDS (64 KB); the two block lists stream
 //            through the CU once, coalesced; each wave merge-intersects 64-key
@@ -20,7 +22,7 @@
 //            (source_1, source_2, shared) edges.
 //
 // Integer set intersection: no MFMA.  The dominant kernel k_join is bound by the
-// HBM/L2 stream of the block lists (12 B per key), see DESIGN.md.
+// HBM/L2 stream of the block lists (8 B per key: rank + posting word), see DESIGN.md.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -60,8 +62,9 @@ void set_error(const std::string& s) { g_error = s; }
 constexpr int TB = 128;       // sources per block (tile edge)
 constexpr int NP = 64;        // value-range parts per block (intra-tile work items)
 constexpr int JW = 8;         // waves per join workgroup
-constexpr int CH = 64;        // keys per chunk = wavefront width
-constexpr u32 MULTI = 0x80000000u;
+constexpr int WIN = 256;      // keys per chunk / LDS window: 4 per lane of a wavefront
+constexpr u32 BIG = 0xE0000000u;      // posting word: more than INLINE_MAX sources, mask index in the low bits
+constexpr u32 INLINE_MAX = 4;         // sources whose 7-bit ids fit into the posting word
 
 // ------------------------------------------------------------------------------------
 // stage 1 kernels
@@ -82,87 +85,140 @@ __global__ void k_tag(const u64* __restrict__ off, const u32* __restrict__ wts, 
 
 template <class V> __device__ inline u32 tag_of(V v) { return (u32)v; }
 
-// flag[e] = 1 when entry e opens a new (block, key) group.
+// After the global sort by key: flag[e] = 1 where a new distinct key starts (0 at e = 0),
+// so that inclusive_scan(flag) is the key's dense rank — an exact, order-preserving
+// 32-bit stand-in for the 64-bit hash.
+__global__ void k_flag_keys(const u64* __restrict__ keys, u32* __restrict__ flag, u64 n) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    flag[e] = (e > 0 && keys[e] != keys[e - 1]) ? 1u : 0u;
+}
+
+// flag[e] = 1 when entry e opens a new (block, rank) group.
 template <class V>
-__global__ void k_heads(const u64* __restrict__ keys, const V* __restrict__ vals, u32* __restrict__ flag, u64 n) {
+__global__ void k_heads(const u32* __restrict__ rk, const V* __restrict__ vals, u32* __restrict__ flag, u64 n) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     u32 f = 1;
-    if (e > 0) f = ((tag_of(vals[e]) >> 8) != (tag_of(vals[e - 1]) >> 8)) || (keys[e] != keys[e - 1]);
+    if (e > 0) f = ((tag_of(vals[e]) >> 8) != (tag_of(vals[e - 1]) >> 8)) || (rk[e] != rk[e - 1]);
     flag[e] = f;
 }
 
-// distinct keys + first entry of each group; estart[Ktot] = n.
-__global__ void k_emit_keys(const u64* __restrict__ keys, const u32* __restrict__ flag, const u32* __restrict__ didx,
-                            u64* __restrict__ bkeys, u32* __restrict__ estart, u32* __restrict__ ktot, u64 n) {
-    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    if (flag[e]) {
-        bkeys[didx[e]] = keys[e];
-        estart[didx[e]] = (u32)e;
-    }
-    if (e == n - 1) {
-        u32 k = didx[e] + flag[e];
+// scal[1] = Ktot (distinct (block, key) groups), estart[Ktot] = n.
+__global__ void k_ktot(const u32* __restrict__ flag, const u32* __restrict__ didx, u32* __restrict__ estart,
+                       u64* __restrict__ scal, u64 n) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        u32 k = didx[n - 1] + flag[n - 1];
         estart[k] = (u32)n;
-        *ktot = k;
+        scal[1] = k;
     }
 }
 
-// first distinct-key index of each block (entries of a block are contiguous).
-__global__ void k_blk_off(const u64* __restrict__ off, const u32* __restrict__ didx, const u32* __restrict__ ktot,
-                          u32* __restrict__ blk_off, u32 nb, u32 n_sources, u64 n) {
+__global__ void k_store_u(const u32* __restrict__ rank_by_key, u64* __restrict__ scal, u64 n) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[2] = (u64)rank_by_key[n - 1] + 1;
+}
+
+// raw (unpadded) first distinct-key index of each block: entries of a block are contiguous.
+__global__ void k_blk_raw(const u64* __restrict__ off, const u32* __restrict__ didx, const u64* __restrict__ scal,
+                          u32* __restrict__ blk_raw, u32 nb, u32 n_sources, u64 n) {
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nb) return;
     u64 s = (u64)b * TB;
     u64 es = off[s < n_sources ? s : n_sources];
-    blk_off[b] = (es < n) ? didx[es] : *ktot;
+    blk_raw[b] = (es < n) ? didx[es] : (u32)scal[1];
 }
 
-__global__ void k_mmsize(const u32* __restrict__ estart, const u32* __restrict__ ktot, u32* __restrict__ mmsz,
-                         u64 cap) {
+// Padded layout of the block lists: every list starts at a multiple of 4 entries and is
+// followed by >= WIN pad entries (rank PAD = +inf), so that any 16-byte-aligned window of
+// WIN entries that starts inside a list is sorted and never runs into the next list.
+__global__ void k_blk_pos(const u32* __restrict__ blk_raw, u32* __restrict__ blk_pos, u64* __restrict__ scal, u32 nb) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        u32 pos = 0;
+        for (u32 b = 0; b < nb; ++b) {
+            blk_pos[b] = pos;
+            u32 cnt = blk_raw[b + 1] - blk_raw[b];
+            pos = ((pos + cnt + 3u) & ~3u) + WIN;
+        }
+        blk_pos[nb] = pos;
+        scal[3] = pos;
+    }
+}
+
+__global__ void k_fill(u32* __restrict__ p, u32 v, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// distinct ranks of every block (padded layout) + first entry of each group.
+template <class V>
+__global__ void k_emit_keys(const u32* __restrict__ rk, const V* __restrict__ vals, const u32* __restrict__ flag,
+                            const u32* __restrict__ didx, const u32* __restrict__ blk_raw,
+                            const u32* __restrict__ blk_pos, u32* __restrict__ brk, u32* __restrict__ estart, u64 n) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    if (flag[e]) {
+        u32 d = didx[e], b = tag_of(vals[e]) >> 8;
+        brk[blk_pos[b] + (d - blk_raw[b])] = rk[e];
+        estart[d] = (u32)e;
+    }
+}
+
+__global__ void k_bigflag(const u32* __restrict__ estart, const u64* __restrict__ scal, u32* __restrict__ big,
+                          u64 cap) {
     u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= cap) return;
     u32 v = 0;
-    if (d < *ktot) {
-        u32 c = estart[d + 1] - estart[d];
-        v = c >= 2 ? c + 1 : 0;
-    }
-    mmsz[d] = v;
+    if (d < scal[1]) v = (estart[d + 1] - estart[d]) > INLINE_MAX ? 1u : 0u;
+    big[d] = v;
 }
 
-// info word per distinct key: singleton -> local id; otherwise MULTI | offset into mm,
-// where mm[off] = count-1 and mm[off+1 ..] = the local ids in ascending order.
+// Posting word of a distinct key (which of the block's 128 sources hold it):
+//   bits 31..29 = c-1 for c <= 4 sources, whose 7-bit local ids sit in bits 0..27
+//   (ascending, 7 bits each);  bits 31..29 = 7 -> more than 4 sources: bits 0..28 index a
+//   128-bit membership mask in `bigmask`.
 template <class V, bool W>
-__global__ void k_emit_info(const u32* __restrict__ estart, const u32* __restrict__ mmoff,
-                            const u32* __restrict__ ktot, const V* __restrict__ vals, u32* __restrict__ info,
-                            u8* __restrict__ mm, u32* __restrict__ bw) {
+__global__ void k_emit_info(const u32* __restrict__ estart, const u32* __restrict__ bigoff,
+                            const u64* __restrict__ scal, const V* __restrict__ vals,
+                            const u32* __restrict__ blk_raw, const u32* __restrict__ blk_pos, u32* __restrict__ info,
+                            uint4* __restrict__ bigmask, u32* __restrict__ bw) {
     u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= *ktot) return;
+    if (d >= scal[1]) return;
     u32 b = estart[d], c = estart[d + 1] - b;
     V v0 = vals[b];
-    if (W) bw[d] = (u32)((u64)v0 >> 32);
-    if (c == 1) {
-        info[d] = tag_of(v0) & 0xFF;
+    u32 blk = tag_of(v0) >> 8;
+    u32 dst = blk_pos[blk] + ((u32)d - blk_raw[blk]);
+    if (W) bw[dst] = (u32)((u64)v0 >> 32);
+    if (c <= INLINE_MAX) {
+        u32 inf = (c - 1) << 29;
+        for (u32 i = 0; i < c; ++i) inf |= (tag_of(vals[b + i]) & 0x7F) << (7 * i);
+        info[dst] = inf;
     } else {
-        u32 o = mmoff[d];
-        info[d] = MULTI | o;
-        mm[o] = (u8)(c - 1);
-        for (u32 i = 0; i < c; ++i) mm[o + 1 + i] = (u8)(tag_of(vals[b + i]) & 0xFF);
+        u32 m[4] = {0, 0, 0, 0};
+        for (u32 i = 0; i < c; ++i) {
+            u32 id = tag_of(vals[b + i]) & 0x7F;
+            m[id >> 5] |= 1u << (id & 31);
+        }
+        u32 o = bigoff[d];
+        info[dst] = BIG | o;
+        bigmask[o] = make_uint4(m[0], m[1], m[2], m[3]);
     }
 }
 
-// part[b][p] = first key of block b that is >= p * step  (p = 0..NP; part[b][NP] = end).
-__global__ void k_part(const u64* __restrict__ bkeys, const u32* __restrict__ blk_off, u32* __restrict__ part,
-                       u32 nb, u64 step) {
+// part[b][p] = position (padded layout) of the first key of block b whose rank is
+// >= p * ceil(U / NP)  (p = 0..NP).  Ranks are dense, so equal rank ranges are equal shares
+// of the distinct keys whatever the distribution of the hash values.
+__global__ void k_part(const u32* __restrict__ brk, const u32* __restrict__ blk_raw, const u32* __restrict__ blk_pos,
+                       const u64* __restrict__ scal, u32* __restrict__ part, u32 nb) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb * (NP + 1)) return;
     u32 b = i / (NP + 1), p = i % (NP + 1);
-    u32 lo = blk_off[b], hi = blk_off[b + 1];
+    u32 lo = blk_pos[b], hi = lo + (blk_raw[b + 1] - blk_raw[b]);
     if (p == NP) { part[i] = hi; return; }
-    u64 v = (u64)p * step;   // NP * step > max key, p * step never overflows
+    u64 step = (scal[2] + NP - 1) / NP;
+    u64 v = (u64)p * step;
     while (lo < hi) {
         u32 mid = lo + ((hi - lo) >> 1);
-        if (bkeys[mid] < v) lo = mid + 1; else hi = mid;
+        if ((u64)brk[mid] < v) lo = mid + 1; else hi = mid;
     }
     part[i] = lo;
 }
@@ -171,12 +227,13 @@ __global__ void k_part(const u64* __restrict__ bkeys, const u32* __restrict__ bl
 // stage 2: the join kernel
 // ------------------------------------------------------------------------------------
 struct JoinArgs {
-    const u64* bkeys;
+    const u32* brk;     // block lists: distinct key ranks, ascending inside a block
     const u32* info;
     const u32* bw;      // NULL -> weight 1
-    const u8* mm;
-    const u32* blk_off; // nb + 1
-    const u32* part;    // nb * (NP + 1)
+    const uint4* bigmask; // 128-bit membership masks of the postings with > 4 sources
+    const u32* blk_raw; // nb + 1: unpadded distinct-key offsets (counts)
+    const u32* blk_pos; // nb + 1: start of every block list in the padded layout
+    const u32* part;    // nb * (NP + 1): positions in the padded layout
     u32 nb;
     u32 n_sources;
     u64 tile_begin;
@@ -199,138 +256,242 @@ __host__ __device__ inline void tile_decode(u64 t, u32 nb, u32& I, u32& J) {
     J = (u32)(i + (long long)(t - tile_row_start((u64)i, nb)));
 }
 
-// members of a posting: singleton id or list in mm.
-struct Members {
-    const u8* p;
-    u32 n;
-    u32 single;
-    __device__ inline u32 get(u32 i) const { return p ? (u32)p[i] : single; }
-};
-__device__ inline Members members_of(u32 info, const u8* __restrict__ mm) {
-    Members m;
-    if (info & MULTI) {
-        const u8* q = mm + (info & ~MULTI);
-        m.n = (u32)q[0] + 1;
-        m.p = q + 1;
-        m.single = 0;
-    } else {
-        m.n = 1;
-        m.p = nullptr;
-        m.single = info;
+// Ranks are < 2^30, so these never equal a real rank; as signed ints they are positive,
+// which keeps the branch-free "b < a" test ((int)(b - a) >> 31) exact.
+constexpr u32 PAD = 0x7FFFFFFFu;     // +inf: tail padding of every block list
+constexpr u32 INF_A = 0x7FFFFFFEu;   // masked A keys / "last key" of a final A chunk
+constexpr u32 INF_B = 0x7FFFFFFFu;   // "last key" of a final B window
+
+// One 256-key chunk of a block list, 4 consecutive ranks per lane (one 16-byte load).
+// Only ranks are streamed; posting words / weights are gathered for matching keys only.
+__device__ inline uint4 load_a(const JoinArgs& a, u32 cbase, u32 pa, u32 ea, int lane) {
+    uint4 k = make_uint4(INF_A, INF_A, INF_A, INF_A);
+    if (cbase < ea) {   // wave-uniform
+        k = reinterpret_cast<const uint4*>(a.brk)[(cbase >> 2) + lane];
+        const u32 p0 = cbase + 4u * lane;
+        // keys outside [pa, ea) belong to a neighbouring part: mask them
+        k.x = (p0 >= pa && p0 < ea) ? k.x : INF_A;
+        k.y = (p0 + 1 >= pa && p0 + 1 < ea) ? k.y : INF_A;
+        k.z = (p0 + 2 >= pa && p0 + 2 < ea) ? k.z : INF_A;
+        k.w = (p0 + 3 >= pa && p0 + 3 < ea) ? k.w : INF_A;
     }
-    return m;
+    return k;
+}
+__device__ inline uint4 load_b(const JoinArgs& a, u32 wbase, u32 eb, int lane) {
+    uint4 k = make_uint4(PAD, PAD, PAD, PAD);
+    // a window that starts inside the part stays sorted: it may run into the next part
+    // (larger keys, harmless because A is masked) and into the +inf tail pads
+    if (wbase < eb) k = reinterpret_cast<const uint4*>(a.brk)[(wbase >> 2) + lane];
+    return k;
+}
+
+// (s < a) as 0/1 without touching VCC (both < 2^31).
+__device__ inline u32 lt(u32 s, u32 a) { return (s - a) >> 31; }
+
+// B window of one wave in LDS: the 256 sorted ranks (leaf level: 64 nodes of 4) plus two
+// inner levels of an implicit 4-ary search tree over the leaves' last keys.  The root
+// (3 separators) lives in SGPRs.  Every level is one conflict-free ds_read_b128.
+struct Window {
+    uint4 leaf[64];   // leaf[l] = ranks 4l .. 4l+3
+    uint4 l2[16];     // l2[m]   = last rank of leaves 4m .. 4m+3
+    uint4 l1[4];      // l1[q]   = last rank of leaves 16q+3, 16q+7, 16q+11, 16q+15
+};
+
+// position (0..255) of the first window entry >= key, and whether it equals key
+__device__ inline u32 window_find(const Window& w, u32 s0, u32 s1, u32 s2, u32 key, bool& hit) {
+    const u32 c0 = lt(s0, key) + lt(s1, key) + lt(s2, key);
+    const uint4 n1 = w.l1[c0];
+    const u32 m = 4u * c0 + lt(n1.x, key) + lt(n1.y, key) + lt(n1.z, key);
+    const uint4 n2 = w.l2[m];
+    const u32 lb = 4u * m + lt(n2.x, key) + lt(n2.y, key) + lt(n2.z, key);
+    const uint4 lf = w.leaf[lb];
+    const u32 c3 = lt(lf.x, key) + lt(lf.y, key) + lt(lf.z, key);
+    hit = (lf.x == key) | (lf.y == key) | (lf.z == key) | (lf.w == key);
+    return 4u * lb + c3;
+}
+
+// ---- applying a match to the LDS tile of pair counters -------------------------------
+// Small postings (<= 4 sources, inline in the posting word): the lane adds its own
+// cross product.  No memory traffic besides the LDS atomics.
+__device__ inline void add_inline(u32* S, u32 ia, u32 ib, u32 w) {
+    const u32 nA = (ia >> 29) + 1, nB = (ib >> 29) + 1;
+    for (u32 x = 0; x < nA; ++x) {
+        const u32 row = ((ia >> (7 * x)) & 127u) * TB;
+        for (u32 y = 0; y < nB; ++y) atomicAdd(&S[row + ((ib >> (7 * y)) & 127u)], w);
+    }
+}
+
+// 128-bit membership mask of a posting word (wave-uniform arguments).
+__device__ inline uint4 posting_mask(u32 inf, const uint4* __restrict__ bigmask) {
+    if (inf >= BIG) return bigmask[inf & ~BIG];
+    u32 m[4] = {0, 0, 0, 0};
+    const u32 n = (inf >> 29) + 1;
+    for (u32 x = 0; x < n; ++x) {
+        u32 id = (inf >> (7 * x)) & 127u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] |= (id >> 5) == (u32)k ? (1u << (id & 31)) : 0u;
+    }
+    return make_uint4(m[0], m[1], m[2], m[3]);
+}
+
+// Large postings: the whole wave expands one match.  Lanes own the columns
+// (lane, lane + 64) of the tile, rows come from a scalar walk over the bits of mask A:
+// every LDS atomic touches 64 consecutive counters (conflict free).
+// SELF: both postings are the same key of the same block -> only pairs row < column.
+template <bool SELF>
+__device__ inline void add_masks(u32* S, uint4 mA, uint4 mB, u32 w, int lane) {
+    const u32 bw0 = lane < 32 ? mB.x : mB.y, bw1 = lane < 32 ? mB.z : mB.w;
+    const bool c0 = (bw0 >> (lane & 31)) & 1u, c1 = (bw1 >> (lane & 31)) & 1u;
+    const u32 words[4] = {mA.x, mA.y, mA.z, mA.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        u32 word = __builtin_amdgcn_readfirstlane(words[k]);
+        while (word) {
+            const u32 r = 32u * k + (u32)__builtin_ctz(word);
+            word &= word - 1;
+            u32* row = S + r * TB;
+            if (c0 && (!SELF || (u32)lane > r)) atomicAdd(&row[lane], w);
+            if (c1 && (!SELF || (u32)lane + 64u > r)) atomicAdd(&row[lane + 64], w);
+        }
+    }
+}
+
+// posting words (and weight) of up to 4 matches per lane, fetched one step ahead of use
+struct Pending {
+    u32 ia[4], ib[4], w[4];
+    bool h[4];
+};
+__device__ inline void pending_clear(Pending& q) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { q.h[j] = false; q.ia[j] = 0; q.ib[j] = 0; q.w[j] = 1; }
+}
+__device__ inline void pending_apply(u32* S, const uint4* __restrict__ bigmask, const Pending& q, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool big = q.h[j] && ((q.ia[j] | q.ib[j]) >= BIG);   // either side has > 4 sources
+        if (q.h[j] && !big) add_inline(S, q.ia[j], q.ib[j], q.w[j]);
+        unsigned long long todo = __ballot(big);
+        while (todo) {   // wave-cooperative expansion, one match at a time
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const u32 ia = __builtin_amdgcn_readlane(q.ia[j], src);
+            const u32 ib = __builtin_amdgcn_readlane(q.ib[j], src);
+            const u32 w = __builtin_amdgcn_readlane(q.w[j], src);
+            add_masks<false>(S, posting_mask(ia, bigmask), posting_mask(ib, bigmask), w, lane);
+        }
+    }
 }
 
 template <bool W>
 __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
+    // 64 KB pair counters + 8 x 1.3 KB B windows: two workgroups per CU (160 KB LDS)
     __shared__ u32 S[TB * TB];
-    __shared__ u64 sBk[JW][CH];
-    __shared__ u32 sBi[JW][CH];
-    __shared__ int s_next;
+    __shared__ Window win[JW];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     u32 I, J;
     tile_decode(a.tile_begin + blockIdx.x, a.nb, I, J);
 
     for (int i = tid; i < TB * TB; i += JW * 64) S[i] = 0;
-    if (tid == 0) s_next = 0;
     __syncthreads();
 
     if (I == J) {
-        // self tile: every key of the block matches itself; only multi-member keys
-        // produce pairs (i < j because postings are ascending).
-        const u32 kb = a.blk_off[I], ke = a.blk_off[I + 1];
-        for (u32 k = kb + tid; k < ke; k += JW * 64) {
-            u32 inf = a.info[k];
-            if (inf & MULTI) {
-                const u32 w = W ? a.bw[k] : 1u;
-                Members m = members_of(inf, a.mm);
-                for (u32 x = 0; x + 1 < m.n; ++x) {
-                    u32 mx = m.p[x];
-                    for (u32 y = x + 1; y < m.n; ++y) atomicAdd(&S[mx * TB + m.p[y]], w);
+        // self tile: every key of the block matches itself; only keys held by >= 2 sources
+        // produce pairs (i < j because posting ids are ascending).
+        const u32 kb = a.blk_pos[I], ke = kb + (a.blk_raw[I + 1] - a.blk_raw[I]);
+        for (u32 k0 = kb; k0 < ke; k0 += JW * 64) {   // uniform trip count: the big path is wave-wide
+            const u32 k = k0 + tid;
+            u32 inf = 0;
+            u32 w = 1;
+            if (k < ke) { inf = a.info[k]; if (W) w = a.bw[k]; }
+            const bool big = inf >= BIG;
+            if (!big) {
+                const u32 n = (inf >> 29) + 1;
+                for (u32 x = 0; x + 1 < n; ++x) {
+                    const u32 row = ((inf >> (7 * x)) & 127u) * TB;
+                    for (u32 y = x + 1; y < n; ++y) atomicAdd(&S[row + ((inf >> (7 * y)) & 127u)], w);
                 }
+            }
+            unsigned long long todo = __ballot(big);
+            while (todo) {
+                const int src = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const u32 si = __builtin_amdgcn_readlane(inf, src);
+                const u32 sw = __builtin_amdgcn_readlane(w, src);
+                const uint4 m = posting_mask(si, a.bigmask);
+                add_masks<true>(S, m, m, sw, lane);
             }
         }
     } else {
         const u32* partI = a.part + (size_t)I * (NP + 1);
         const u32* partJ = a.part + (size_t)J * (NP + 1);
-        u64* myBk = sBk[wv];
-        u32* myBi = sBi[wv];
-        while (true) {
-            int p = 0;
-            if (lane == 0) p = atomicAdd(&s_next, 1);
-            p = __builtin_amdgcn_readfirstlane(p);
-            if (p >= NP) break;
-            u32 pa = partI[p], ea = partI[p + 1], pb = partJ[p], eb = partJ[p + 1];
+        Window& wn = win[wv];
+        u32* l2w = reinterpret_cast<u32*>(wn.l2);
+        u32* l1w = reinterpret_cast<u32*>(wn.l1);
+        // rank-range parts are equal shares of the key space: static round-robin over waves
+        for (int p = wv; p < NP; p += JW) {
+            const u32 pa = __builtin_amdgcn_readfirstlane(partI[p]);
+            const u32 ea = __builtin_amdgcn_readfirstlane(partI[p + 1]);
+            const u32 pb = __builtin_amdgcn_readfirstlane(partJ[p]);
+            const u32 eb = __builtin_amdgcn_readfirstlane(partJ[p + 1]);
             if (pa >= ea || pb >= eb) continue;
 
-            // current chunks (A: one key per lane; B: staged in LDS, padded with its last key)
-            u32 na = min((u32)CH, ea - pa), nbk = min((u32)CH, eb - pb);
-            u64 ka = 0; u32 ia = 0, wa = 1;
-            if (lane < (int)na) { ka = a.bkeys[pa + lane]; ia = a.info[pa + lane]; if (W) wa = a.bw[pa + lane]; }
-            {
-                u32 l = min((u32)lane, nbk - 1);
-                myBk[lane] = a.bkeys[pb + l];
-                myBi[lane] = a.info[pb + l];
-            }
-            // prefetched next chunks
-            u64 ka_n = 0, kb_n = 0; u32 ia_n = 0, wa_n = 1, ib_n = 0;
-            u32 na_n = 0, nb_n = 0;
-            {
-                u32 qa = pa + na;
-                na_n = qa < ea ? min((u32)CH, ea - qa) : 0;
-                if (lane < (int)na_n) { ka_n = a.bkeys[qa + lane]; ia_n = a.info[qa + lane]; if (W) wa_n = a.bw[qa + lane]; }
-                u32 qb = pb + nbk;
-                nb_n = qb < eb ? min((u32)CH, eb - qb) : 0;
-                if (nb_n) { u32 l = min((u32)lane, nb_n - 1); kb_n = a.bkeys[qb + l]; ib_n = a.info[qb + l]; }
-            }
+            u32 ca = pa & ~3u, cb = pb & ~3u;   // 16-byte aligned bases of the current chunk / window
+            uint4 A0 = load_a(a, ca, pa, ea, lane);
+            uint4 A1 = load_a(a, ca + WIN, pa, ea, lane);
+            uint4 A2 = load_a(a, ca + 2 * WIN, pa, ea, lane);
+            uint4 B0 = load_b(a, cb, eb, lane);
+            uint4 B1 = load_b(a, cb + WIN, eb, lane);
+            uint4 B2 = load_b(a, cb + 2 * WIN, eb, lane);
+            Pending pend;
+            pending_clear(pend);
+            bool newB = true;
+            u32 s0 = 0, s1 = 0, s2 = 0;
             while (true) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                // 64 x 64 compare: every lane's A key against the broadcast B chunk
-                int hit = -1;
-#pragma unroll
-                for (int k = 0; k < CH; ++k) {
-                    u64 b = myBk[k];
-                    if (ka == b) hit = k;
+                if (newB) {   // (re)build the window of this wave
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    wn.leaf[lane] = B0;
+                    l2w[lane] = B0.w;
+                    if ((lane & 3) == 3) l1w[lane >> 2] = B0.w;
+                    s0 = __builtin_amdgcn_readlane(B0.w, 15);
+                    s1 = __builtin_amdgcn_readlane(B0.w, 31);
+                    s2 = __builtin_amdgcn_readlane(B0.w, 47);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 }
-                if (lane < (int)na && hit >= 0) {
-                    hit = min(hit, (int)nbk - 1);   // padded tail duplicates the last key
-                    u32 ib = myBi[hit];
-                    if (!((ia | ib) & MULTI)) {
-                        atomicAdd(&S[ia * TB + ib], wa);
-                    } else {
-                        Members mA = members_of(ia, a.mm), mB = members_of(ib, a.mm);
-                        for (u32 x = 0; x < mA.n; ++x) {
-                            u32 row = mA.get(x) * TB;
-                            for (u32 y = 0; y < mB.n; ++y) atomicAdd(&S[row + mB.get(y)], wa);
-                        }
-                    }
-                }
-                // advance the chunk(s) with the smaller last key
-                u64 aLast = __shfl(ka, (int)na - 1);
-                u64 bLast = myBk[nbk - 1];
-                bool advA = aLast <= bLast, advB = bLast <= aLast;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // each lane looks its 4 A keys up in the 256-key B window
+                bool h0, h1, h2, h3;
+                const u32 p0 = window_find(wn, s0, s1, s2, A0.x, h0);
+                const u32 p1 = window_find(wn, s0, s1, s2, A0.y, h1);
+                const u32 p2 = window_find(wn, s0, s1, s2, A0.z, h2);
+                const u32 p3 = window_find(wn, s0, s1, s2, A0.w, h3);
+                // matches of the previous step: their posting words have arrived by now
+                pending_apply(S, a.bigmask, pend, lane);
+                // fetch the posting words of this step's matches (consumed next step)
+                const u32 qa = ca + 4u * lane;
+                pend.h[0] = h0; pend.h[1] = h1; pend.h[2] = h2; pend.h[3] = h3;
+                if (h0) { pend.ia[0] = a.info[qa];     pend.ib[0] = a.info[cb + p0]; if (W) pend.w[0] = a.bw[qa]; }
+                if (h1) { pend.ia[1] = a.info[qa + 1]; pend.ib[1] = a.info[cb + p1]; if (W) pend.w[1] = a.bw[qa + 1]; }
+                if (h2) { pend.ia[2] = a.info[qa + 2]; pend.ib[2] = a.info[cb + p2]; if (W) pend.w[2] = a.bw[qa + 2]; }
+                if (h3) { pend.ia[3] = a.info[qa + 3]; pend.ib[3] = a.info[cb + p3]; if (W) pend.w[3] = a.bw[qa + 3]; }
+                // advance whichever side ends first (both on a tie)
+                const bool afin = ca + WIN >= ea, bfin = cb + WIN >= eb;
+                const u32 aLast = afin ? INF_A : (u32)__builtin_amdgcn_readlane(A0.w, 63);
+                const u32 bLast = bfin ? INF_B : (u32)__builtin_amdgcn_readlane(B0.w, 63);
+                const bool advA = aLast <= bLast, advB = bLast <= aLast;
+                if ((advA && afin) || (advB && bfin)) break;
+                newB = advB;
                 if (advA) {
-                    pa += na;
-                    if (pa >= ea) break;
-                    na = na_n; ka = ka_n; ia = ia_n; wa = wa_n;
-                    u32 qa = pa + na;
-                    na_n = qa < ea ? min((u32)CH, ea - qa) : 0;
-                    ka_n = 0; ia_n = 0; wa_n = 1;
-                    if (lane < (int)na_n) { ka_n = a.bkeys[qa + lane]; ia_n = a.info[qa + lane]; if (W) wa_n = a.bw[qa + lane]; }
+                    ca += WIN;
+                    A0 = A1; A1 = A2;
+                    A2 = load_a(a, ca + 2 * WIN, pa, ea, lane);
                 }
                 if (advB) {
-                    pb += nbk;
-                    if (pb >= eb) break;
-                    nbk = nb_n;
-                    myBk[lane] = kb_n;
-                    myBi[lane] = ib_n;
-                    u32 qb = pb + nbk;
-                    nb_n = qb < eb ? min((u32)CH, eb - qb) : 0;
-                    if (nb_n) { u32 l = min((u32)lane, nb_n - 1); kb_n = a.bkeys[qb + l]; ib_n = a.info[qb + l]; }
+                    cb += WIN;
+                    B0 = B1; B1 = B2;
+                    B2 = load_b(a, cb + 2 * WIN, eb, lane);
                 }
             }
+            pending_apply(S, a.bigmask, pend, lane);
         }
     }
     __syncthreads();
@@ -390,9 +551,9 @@ struct ksp_engine {
     std::vector<u64> h_off;
     std::vector<u32> h_blk_off;   // distinct-key offsets of the block lists (host copy)
     // workspace
-    ksp::Buf d_off, KA, KB, VA, VB, tmp, bkeys, info, bw, mm, blk_off, part, scalars, count;
+    ksp::Buf d_off, KA, KB, VA, VB, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, part, scalars, count;
     unsigned long long* h_count = nullptr;   // pinned
-    u64* h_scal = nullptr;                   // pinned: [0] max key, [1] ktot
+    u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     ksp_stats st{};
 };
@@ -406,34 +567,37 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     typedef typename std::conditional<W, u64, u32>::type V;
     const u64 n = e->n_entries;
     const u32 N = e->n_sources, nb = e->nb;
+    const u64 lmax = n + (u64)nb * (WIN + 4) + 4 * WIN;   // upper bound of the padded layout (+ read slack)
     int rc;
     if ((rc = e->KA.ensure((n + 4) * 8))) return rc;
     if ((rc = e->KB.ensure((n + 4) * 8))) return rc;
     if ((rc = e->VA.ensure((n + 4) * sizeof(V)))) return rc;
     if ((rc = e->VB.ensure((n + 4) * sizeof(V)))) return rc;
-    if ((rc = e->bkeys.ensure((n + 4) * 8))) return rc;
-    if ((rc = e->info.ensure((n + 4) * 4))) return rc;
-    if (W && (rc = e->bw.ensure((n + 4) * 4))) return rc;
-    if ((rc = e->mm.ensure(n + n / 2 + 64))) return rc;
-    if ((rc = e->blk_off.ensure(((size_t)nb + 2) * 4))) return rc;
+    if ((rc = e->bkeys.ensure(lmax * 4))) return rc;
+    if ((rc = e->info.ensure(lmax * 4))) return rc;
+    if (W && (rc = e->bw.ensure(lmax * 4))) return rc;
+    if ((rc = e->mm.ensure((n / (INLINE_MAX + 1) + 16) * 16))) return rc;   // 128-bit masks of big postings
+    if ((rc = e->blk_raw.ensure(((size_t)nb + 2) * 4))) return rc;
+    if ((rc = e->blk_pos.ensure(((size_t)nb + 2) * 4))) return rc;
     if ((rc = e->part.ensure(((size_t)nb + 1) * (NP + 1) * 4))) return rc;
     if ((rc = e->scalars.ensure(64))) return rc;
 
     u64* KA = e->KA.as<u64>();
-    u64* KB = e->KB.as<u64>();
     V* VA = e->VA.as<V>();
     V* VB = e->VB.as<V>();
     u64* d_off = e->d_off.as<u64>();
-    u64* d_max = e->scalars.as<u64>();
-    u32* d_ktot = (u32*)(e->scalars.as<u64>() + 1);
+    u64* scal = e->scalars.as<u64>();   // [0] max key, [1] Ktot, [2] U, [3] padded length
+    u32* blk_raw = e->blk_raw.as<u32>();
+    u32* blk_pos = e->blk_pos.as<u32>();
+    const unsigned bs = 256;
 
     // key range (one 8-byte D2H, unless the caller passed key_bits)
     size_t tb = 0;
     if (e->key_bits <= 0) {
-        KSP_HIP(rocprim::reduce(nullptr, tb, d_keys, d_max, (u64)0, n, rocprim::maximum<u64>(), st));
+        KSP_HIP(rocprim::reduce(nullptr, tb, d_keys, scal, (u64)0, n, rocprim::maximum<u64>(), st));
         if ((rc = e->tmp.ensure(tb))) return rc;
-        KSP_HIP(rocprim::reduce(e->tmp.p, tb, d_keys, d_max, (u64)0, n, rocprim::maximum<u64>(), st));
-        KSP_HIP(hipMemcpyAsync(e->h_scal, d_max, 8, hipMemcpyDeviceToHost, st));
+        KSP_HIP(rocprim::reduce(e->tmp.p, tb, d_keys, scal, (u64)0, n, rocprim::maximum<u64>(), st));
+        KSP_HIP(hipMemcpyAsync(e->h_scal, scal, 8, hipMemcpyDeviceToHost, st));
         KSP_HIP(hipStreamSynchronize(st));
         u64 mx = e->h_scal[0];
         int bits = 1;
@@ -446,43 +610,54 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
 
     hipLaunchKernelGGL((k_tag<W>), dim3(N), dim3(256), 0, st, d_off, d_w, W ? nullptr : (u32*)VA,
                        W ? (u64*)VA : nullptr);
-    // sort 1: by key (payload = tag [+weight])
+    // sort 1: all entries by key (payload = tag [+weight]):  d_keys,VA -> KA,VB
     tb = 0;
     KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_keys, KA, VA, VB, n, 0, kbits, st));
     if ((rc = e->tmp.ensure(tb))) return rc;
     KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, d_keys, KA, VA, VB, n, 0, kbits, st));
-    // sort 2: stable by block id (bits [8, 8+bbits) of the tag), payload = key
+    // dense rank of every key: exact 32-bit stand-in for the hash
+    u32* kflag = (u32*)e->KB.p;            // n
+    u32* krank = (u32*)e->KB.p + (n + 2);  // n
+    hipLaunchKernelGGL(k_flag_keys, dim3(grid_for(n, bs)), dim3(bs), 0, st, KA, kflag, n);
     tb = 0;
-    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, VB, VA, KA, KB, n, 8, 8 + bbits, st));
+    KSP_HIP(rocprim::inclusive_scan(nullptr, tb, kflag, krank, n, rocprim::plus<u32>(), st));
     if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, VB, VA, KA, KB, n, 8, 8 + bbits, st));
-    // now: KB = keys sorted by (block, key); VA = tags in the same order.  KA, VB are free.
+    KSP_HIP(rocprim::inclusive_scan(e->tmp.p, tb, kflag, krank, n, rocprim::plus<u32>(), st));
+    hipLaunchKernelGGL(k_store_u, dim3(1), dim3(64), 0, st, krank, scal, n);
+    // sort 2: stable by block id (bits [8, 8+bbits) of the tag), payload = rank:  VB,krank -> VA,rk2
+    u32* rk2 = (u32*)KA;                   // KA (sorted keys) is dead from here on
+    tb = 0;
+    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, VB, VA, krank, rk2, n, 8, 8 + bbits, st));
+    if ((rc = e->tmp.ensure(tb))) return rc;
+    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, VB, VA, krank, rk2, n, 8, 8 + bbits, st));
+    // now: rk2 = ranks sorted by (block, rank); VA = tags in the same order.  KB, VB are free.
     u32* flag = (u32*)VB;
-    u32* didx = (u32*)KA;                 // n u32
-    u32* estart = (u32*)KA + (n + 2);     // up to n+1 u32
-    const unsigned bs = 256;
-    hipLaunchKernelGGL((k_heads<V>), dim3(grid_for(n, bs)), dim3(bs), 0, st, KB, VA, flag, n);
+    u32* didx = (u32*)e->KB.p;             // n
+    u32* estart = (u32*)e->KB.p + (n + 2); // up to n+1
+    hipLaunchKernelGGL((k_heads<V>), dim3(grid_for(n, bs)), dim3(bs), 0, st, rk2, VA, flag, n);
     tb = 0;
     KSP_HIP(rocprim::exclusive_scan(nullptr, tb, flag, didx, (u32)0, n, rocprim::plus<u32>(), st));
     if ((rc = e->tmp.ensure(tb))) return rc;
     KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, flag, didx, (u32)0, n, rocprim::plus<u32>(), st));
-    hipLaunchKernelGGL(k_emit_keys, dim3(grid_for(n, bs)), dim3(bs), 0, st, KB, flag, didx, e->bkeys.as<u64>(),
-                       estart, d_ktot, n);
-    hipLaunchKernelGGL(k_blk_off, dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, d_off, didx, d_ktot,
-                       e->blk_off.as<u32>(), nb, N, n);
-    u32* mmsz = flag;     // flags are dead now
-    u32* mmoff = didx;    // didx is dead after k_blk_off
-    hipLaunchKernelGGL(k_mmsize, dim3(grid_for(n, bs)), dim3(bs), 0, st, estart, d_ktot, mmsz, n);
+    hipLaunchKernelGGL(k_ktot, dim3(1), dim3(64), 0, st, flag, didx, estart, scal, n);
+    hipLaunchKernelGGL(k_blk_raw, dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, d_off, didx, scal, blk_raw, nb,
+                       N, n);
+    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, blk_raw, blk_pos, scal, nb);
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(lmax, bs)), dim3(bs), 0, st, e->bkeys.as<u32>(), PAD, lmax);
+    hipLaunchKernelGGL((k_emit_keys<V>), dim3(grid_for(n, bs)), dim3(bs), 0, st, rk2, VA, flag, didx, blk_raw,
+                       blk_pos, e->bkeys.as<u32>(), estart, n);
+    u32* mmsz = flag;                      // flags are dead now
+    u32* mmoff = (u32*)KA;                 // rk2 is dead after k_emit_keys
+    hipLaunchKernelGGL(k_bigflag, dim3(grid_for(n, bs)), dim3(bs), 0, st, estart, scal, mmsz, n);
     tb = 0;
     KSP_HIP(rocprim::exclusive_scan(nullptr, tb, mmsz, mmoff, (u32)0, n, rocprim::plus<u32>(), st));
     if ((rc = e->tmp.ensure(tb))) return rc;
     KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, mmsz, mmoff, (u32)0, n, rocprim::plus<u32>(), st));
-    hipLaunchKernelGGL((k_emit_info<V, W>), dim3(grid_for(n, bs)), dim3(bs), 0, st, estart, mmoff, d_ktot, VA,
-                       e->info.as<u32>(), e->mm.as<u8>(), W ? e->bw.as<u32>() : nullptr);
-    // value-range partition of every block list
-    u64 step = (kbits >= 64 ? (~0ull >> 6) : (((1ull << kbits) - 1) >> 6)) + 1;   // NP = 64 = 2^6
-    hipLaunchKernelGGL(k_part, dim3(grid_for((u64)nb * (NP + 1), bs)), dim3(bs), 0, st, e->bkeys.as<u64>(),
-                       e->blk_off.as<u32>(), e->part.as<u32>(), nb, step);
+    hipLaunchKernelGGL((k_emit_info<V, W>), dim3(grid_for(n, bs)), dim3(bs), 0, st, estart, mmoff, scal, VA,
+                       blk_raw, blk_pos, e->info.as<u32>(), e->mm.as<uint4>(), W ? e->bw.as<u32>() : nullptr);
+    // rank-range partition of every block list
+    hipLaunchKernelGGL(k_part, dim3(grid_for((u64)nb * (NP + 1), bs)), dim3(bs), 0, st, e->bkeys.as<u32>(),
+                       blk_raw, blk_pos, scal, e->part.as<u32>(), nb);
     KSP_HIP(hipGetLastError());
     return KSP_OK;
 }
@@ -526,7 +701,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->tmp, &e->bkeys, &e->info,
-                        &e->bw, &e->mm, &e->blk_off, &e->part, &e->scalars, &e->count};
+                        &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->part, &e->scalars, &e->count};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
@@ -573,9 +748,9 @@ int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_
     KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 8, hipMemcpyDeviceToHost, st));
     KSP_HIP(hipStreamSynchronize(st));
     KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
-    e->st.n_block_keys = (u32)e->h_scal[1];
+    e->st.n_block_keys = e->h_scal[1];
     e->h_blk_off.resize((size_t)e->nb + 1);
-    KSP_HIP(hipMemcpy(e->h_blk_off.data(), e->blk_off.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
+    KSP_HIP(hipMemcpy(e->h_blk_off.data(), e->blk_raw.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
     e->st.key_bits = e->key_bits;
     e->built = true;
     return KSP_OK;
@@ -623,11 +798,12 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     int rc;
     if ((rc = e->count.ensure(64))) return rc;
     JoinArgs a;
-    a.bkeys = e->bkeys.as<u64>();
+    a.brk = e->bkeys.as<u32>();
     a.info = e->info.as<u32>();
     a.bw = e->weighted ? e->bw.as<u32>() : nullptr;
-    a.mm = e->mm.as<u8>();
-    a.blk_off = e->blk_off.as<u32>();
+    a.bigmask = e->mm.as<uint4>();
+    a.blk_raw = e->blk_raw.as<u32>();
+    a.blk_pos = e->blk_pos.as<u32>();
     a.part = e->part.as<u32>();
     a.nb = e->nb;
     a.n_sources = e->n_sources;
@@ -649,8 +825,8 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     e->st.last_tiles = tile_end - tile_begin;
     e->st.last_pairs = ksp_engine_tile_pairs(e, tile_begin, tile_end);
     e->st.last_edges = *h_count;
-    {   // bytes the kernel streams: keys (8 B) + info (4 B) [+ weight 4 B] of both lists; self tiles read info only
-        const u64 per = e->weighted ? 16 : 12;
+    {   // bytes the kernel streams from both block lists; self tiles read info [+ weight] only
+        const u64 per = 4;   // only the 32-bit ranks are streamed; posting words are gathered on matches
         u64 bytes = 0;
         for (u64 t = tile_begin; t < tile_end;) {
             u32 I, J;
@@ -682,7 +858,7 @@ int ksp_engine_get_stats(const ksp_engine* e, ksp_stats* out) {
 int ksp_engine_block_key_counts(const ksp_engine* e, uint32_t* h_blk_off /* nb+1 */) {
     if (!e || !h_blk_off) return KSP_E_ARG;
     if (!e->nb || !e->n_entries) return KSP_OK;
-    KSP_HIP(hipMemcpy(h_blk_off, e->blk_off.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
+    KSP_HIP(hipMemcpy(h_blk_off, e->blk_raw.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
     return KSP_OK;
 }
 
