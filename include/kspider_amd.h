@@ -103,6 +103,15 @@ void ksp_free(void* p);
  * PREFIX_kSpider_pairwise.tsv.  Device = $KSPIDER_DEVICE (default 0).                  */
 int kspider_pairwise(const char* index_prefix, int user_threads);
 
+/* ---- host-only diagnostics (no GPU needed) -------------------------------------------
+ * ksp_index_info: parse the three index files and report what the reader detected:
+ * out[0] colours, out[1] groups, out[2] colour-count entries, out[3] sum of sources over
+ * colours, out[4] phmap Group::kWidth (16/8), out[5] 1 if a growth_left trailer is present.
+ * ksp_format_float: text of a float as `std::ostream << float` prints it
+ * (src/pairwise.cpp:266-273); buf must hold 32 bytes; returns the length.             */
+int ksp_index_info(const char* index_prefix, uint64_t out[6]);
+int ksp_format_float(float value, char* buf);
+
 #ifdef __cplusplus
 }
 #endif

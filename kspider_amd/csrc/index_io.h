@@ -1,0 +1,44 @@
+// Reader for the reference's on-disk index (phmap binary dumps) and writers for its two
+// TSV outputs.  Host-only C++.
+#ifndef KSPIDER_INDEX_IO_H
+#define KSPIDER_INDEX_IO_H
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+namespace ksp {
+
+struct IndexData {
+    // colour -> sources after the reference's uint32 narrowing + insert_or_assign
+    // (src/pairwise.cpp:103,109), in first-insertion (file) order
+    std::vector<std::pair<uint32_t, std::vector<uint32_t>>> colors;
+    // colour -> #k-mers, both narrowed to uint32 (src/pairwise.cpp:119)
+    std::unordered_map<uint32_t, uint32_t> colors_count;
+    // groupID -> k-mer count in table slot order (iteration order of src/pairwise.cpp:175)
+    std::vector<std::pair<uint32_t, uint32_t>> kmer_slots;
+    int kwidth = 16;       // detected phmap Group::kWidth
+    bool trailer = false;  // detected trailing growth_left word
+};
+
+// Throws std::runtime_error (message names the file) on missing / malformed input.
+void load_index(const std::string& prefix, IndexData& out);
+
+// PREFIX_kSpider_seqToKmersNo.tsv  (src/pairwise.cpp:173-180)
+void write_seq_to_kmers(const std::string& prefix, const IndexData& ix);
+
+struct EdgeRow {
+    uint32_t source_1, source_2;
+    uint64_t shared;
+};
+// PREFIX_kSpider_pairwise.tsv (src/pairwise.cpp:242-275); rows must already be in the
+// order they are to be written.  n1/n2 = k-mer counts of the two sources.
+void write_pairwise_tsv(const std::string& prefix, const std::vector<EdgeRow>& rows,
+                        const std::unordered_map<uint32_t, uint32_t>& kmer_count, int threads);
+
+// "%g"-style text of a float exactly as `std::ostream << float` prints it.
+int format_float(char* buf, float v);
+
+}  // namespace ksp
+#endif

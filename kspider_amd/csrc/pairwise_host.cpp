@@ -1,0 +1,193 @@
+// kSpider::pairwise() drop-in: host side.
+//
+// Mirrors /root/reference/src/pairwise.cpp:123-276 phase by phase:
+//   :127-129  load colour -> sources            -> ksp::load_index
+//   :136-137  load colour counts                -> ksp::load_index
+//   :166-181  load k-mer counts, write seqToKmersNo.tsv
+//   :194-237  accumulate shared k-mers per pair -> MI355X engine (engine.hip)
+//   :242-275  write pairwise.tsv (float maths + formatting on the host)
+// The same progress lines go to stdout.
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/kSpider.hpp"
+#include "../../include/kspider_amd.h"
+#include "engine_internal.h"
+#include "index_io.h"
+
+namespace {
+
+typedef std::chrono::high_resolution_clock Clock;
+double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
+
+int run_pairwise(const std::string& prefix, int user_threads) {
+    auto t0 = Clock::now();
+    ksp::IndexData ix;
+    ksp::load_index(prefix, ix);
+    std::cout << "mapping colors to groups: " << since(t0) << " secs" << std::endl;
+    t0 = Clock::now();
+    std::cout << "parsing index colors: " << since(t0) << " secs" << std::endl;
+    t0 = Clock::now();
+    ksp::write_seq_to_kmers(prefix, ix);
+    std::unordered_map<uint32_t, uint32_t> kmer_count;
+    for (auto& s : ix.kmer_slots) kmer_count[s.first] = s.second;
+    std::cout << "kmer counting: " << since(t0) << " secs" << std::endl;
+
+    t0 = Clock::now();
+    // dense source index = rank of the group ID, so that index order == ID order and the
+    // engine's (i < j) is the reference's ascending(source_1, source_2) (:73-78, :218)
+    std::vector<uint32_t> ids;
+    for (auto& c : ix.colors) ids.insert(ids.end(), c.second.begin(), c.second.end());
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    const uint32_t N = (uint32_t)ids.size();
+    auto dense = [&](uint32_t g) { return (uint32_t)(std::lower_bound(ids.begin(), ids.end(), g) - ids.begin()); };
+
+    // colours in ascending id order -> every source's run of colour ids is sorted
+    std::vector<uint32_t> order(ix.colors.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(),
+              [&](uint32_t a, uint32_t b) { return ix.colors[a].first < ix.colors[b].first; });
+    std::vector<uint64_t> offsets((size_t)N + 1, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> zero_pairs;   // pairs touched only through weight-0 colours
+    std::vector<uint64_t> wsum((size_t)N, 0);
+    std::vector<uint32_t> weight_of(ix.colors.size(), 0);
+    for (size_t ci = 0; ci < ix.colors.size(); ++ci) {
+        auto& c = ix.colors[ci];
+        auto it = ix.colors_count.find(c.first);   // colorsCount[item.first] (:221): 0 when absent
+        const uint32_t w = it == ix.colors_count.end() ? 0 : it->second;
+        weight_of[ci] = w;
+        if (c.second.size() < 2) continue;          // a colour with one source produces no pair
+        if (w == 0) {
+            // the reference still creates the pair entries (with += 0): remember them
+            for (size_t x = 0; x < c.second.size(); ++x)
+                for (size_t y = x + 1; y < c.second.size(); ++y) {
+                    uint32_t a = c.second[x], b = c.second[y];
+                    if (a > b) std::swap(a, b);
+                    if (a != b) zero_pairs.emplace_back(a, b);
+                }
+            continue;
+        }
+        for (uint32_t g : c.second) {
+            offsets[dense(g) + 1]++;
+            wsum[dense(g)] += w;
+        }
+    }
+    for (uint32_t s = 0; s < N; ++s) {
+        if (wsum[s] >= (1ull << 32))
+            throw std::runtime_error("kspider_amd: colour weights of group " + std::to_string(ids[s]) +
+                                     " sum to >= 2^32 (32-bit pair counters would overflow)");
+        offsets[s + 1] += offsets[s];
+    }
+    const uint64_t E = offsets[N];
+    std::vector<uint64_t> keys(E);
+    std::vector<uint32_t> wts(E);
+    {
+        std::vector<uint64_t> cur(offsets.begin(), offsets.end() - 1);
+        for (uint32_t ci : order) {
+            auto& c = ix.colors[ci];
+            if (c.second.size() < 2 || weight_of[ci] == 0) continue;
+            for (uint32_t g : c.second) {
+                uint64_t at = cur[dense(g)]++;
+                keys[at] = c.first;
+                wts[at] = weight_of[ci];
+            }
+        }
+    }
+    // duplicates of one source inside a colour cannot occur (flat_hash_set), but two colours
+    // may narrow to the same uint32 id only via insert_or_assign, which load_index resolved.
+
+    int device = 0;
+    if (const char* d = std::getenv("KSPIDER_DEVICE")) device = std::atoi(d);
+    ksp_edge* edges = nullptr;
+    uint64_t n_edges = 0;
+    ksp_stats st;
+    int rc = ksp_pairwise_host(keys.data(), wts.data(), offsets.data(), N, device, &edges, &n_edges, &st);
+    if (rc != KSP_OK) return rc;
+    std::vector<ksp::EdgeRow> rows;
+    rows.reserve(n_edges + zero_pairs.size());
+    for (uint64_t i = 0; i < n_edges; ++i)
+        rows.push_back(ksp::EdgeRow{ids[edges[i].source_1], ids[edges[i].source_2], edges[i].shared});
+    ksp_free(edges);
+    if (!zero_pairs.empty()) {
+        std::sort(zero_pairs.begin(), zero_pairs.end());
+        zero_pairs.erase(std::unique(zero_pairs.begin(), zero_pairs.end()), zero_pairs.end());
+        const size_t nreal = rows.size();
+        for (auto& zp : zero_pairs) {
+            auto it = std::lower_bound(rows.begin(), rows.begin() + nreal, zp,
+                                       [](const ksp::EdgeRow& r, const std::pair<uint32_t, uint32_t>& k) {
+                                           return r.source_1 != k.first ? r.source_1 < k.first : r.source_2 < k.second;
+                                       });
+            if (it == rows.begin() + nreal || it->source_1 != zp.first || it->source_2 != zp.second)
+                rows.push_back(ksp::EdgeRow{zp.first, zp.second, 0});
+        }
+        std::sort(rows.begin(), rows.end(), [](const ksp::EdgeRow& a, const ksp::EdgeRow& b) {
+            return a.source_1 != b.source_1 ? a.source_1 < b.source_1 : a.source_2 < b.source_2;
+        });
+    }
+    std::cout << "pairwise hashmap construction: " << since(t0) << " secs" << std::endl;
+    std::cout << "writing pairwise matrix to " << prefix << "_kSpider_pairwise.tsv" << std::endl;
+    ksp::write_pairwise_tsv(prefix, rows, kmer_count, user_threads);
+    if (std::getenv("KSPIDER_VERBOSE"))
+        std::cout << "kspider_amd: sources=" << N << " colour-entries=" << E << " pairs=" << rows.size()
+                  << " build_ms=" << st.ms_build << " join_ms=" << st.ms_join << std::endl;
+    return KSP_OK;
+}
+
+}  // namespace
+
+extern "C" int kspider_pairwise(const char* index_prefix, int user_threads) {
+    if (!index_prefix) {
+        ksp::set_error("kspider_pairwise: index_prefix is NULL");
+        return KSP_E_ARG;
+    }
+    try {
+        return run_pairwise(index_prefix, user_threads < 1 ? 1 : user_threads);
+    } catch (const std::bad_alloc&) {
+        ksp::set_error("kspider_pairwise: out of host memory");
+        return KSP_E_LIMIT;
+    } catch (const std::exception& e) {
+        ksp::set_error(e.what());
+        const std::string m = e.what();
+        return m.find("2^32") != std::string::npos ? KSP_E_LIMIT : KSP_E_IO;
+    }
+}
+
+extern "C" int ksp_index_info(const char* index_prefix, uint64_t out[6]) {
+    if (!index_prefix || !out) {
+        ksp::set_error("ksp_index_info: NULL argument");
+        return KSP_E_ARG;
+    }
+    try {
+        ksp::IndexData ix;
+        ksp::load_index(index_prefix, ix);
+        uint64_t m = 0;
+        for (auto& c : ix.colors) m += c.second.size();
+        out[0] = ix.colors.size();
+        out[1] = ix.kmer_slots.size();
+        out[2] = ix.colors_count.size();
+        out[3] = m;
+        out[4] = (uint64_t)ix.kwidth;
+        out[5] = ix.trailer ? 1 : 0;
+        return KSP_OK;
+    } catch (const std::exception& e) {
+        ksp::set_error(e.what());
+        return KSP_E_IO;
+    }
+}
+
+extern "C" int ksp_format_float(float value, char* buf) { return buf ? ksp::format_float(buf, value) : 0; }
+
+namespace kSpider {
+void pairwise(std::string index_prefix, int user_threads) {
+    if (kspider_pairwise(index_prefix.c_str(), user_threads) != KSP_OK) throw std::runtime_error(ksp_last_error());
+}
+}  // namespace kSpider

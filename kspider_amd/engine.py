@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "ksp_last_error", "ksp_device_count", "ksp_engine_create", "ksp_engine_destroy",
     "ksp_engine_build_blocks", "ksp_engine_num_tiles", "ksp_engine_tile_pairs", "ksp_engine_join",
     "ksp_engine_get_stats", "ksp_device_malloc", "ksp_device_free", "ksp_memcpy_h2d", "ksp_memcpy_d2h",
-    "ksp_pairwise_host", "ksp_free", "kspider_pairwise",
+    "ksp_pairwise_host", "ksp_free", "kspider_pairwise", "ksp_index_info", "ksp_format_float",
 ]
 
 
@@ -79,8 +79,9 @@ def lib():
                                         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(Stats)]
         L.ksp_free.argtypes = [ctypes.c_void_p]
         L.ksp_free.restype = None
-        if hasattr(L, 'kspider_pairwise'):  # TEMP until pairwise_host.cpp lands
-            L.kspider_pairwise.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        L.kspider_pairwise.argtypes = [ctypes.c_char_p, ctypes.c_int]
+        L.ksp_index_info.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
+        L.ksp_format_float.argtypes = [ctypes.c_float, ctypes.c_char_p]
         _lib = L
     return _lib
 
@@ -113,6 +114,23 @@ def pairwise_host(keys: np.ndarray, offsets: np.ndarray, weights: np.ndarray | N
     finally:
         lib().ksp_free(out)
     return edges, st.as_dict()
+
+
+def pairwise(index_prefix: str, user_threads: int = 1) -> None:
+    """kSpider::pairwise(index_prefix, user_threads) through the C ABI (reference: kSpider.hpp:11)."""
+    _check(lib().kspider_pairwise(os.fsencode(index_prefix), int(user_threads)))
+
+
+def index_info(index_prefix: str) -> dict:
+    out = (ctypes.c_uint64 * 6)()
+    _check(lib().ksp_index_info(os.fsencode(index_prefix), out))
+    return dict(colors=out[0], groups=out[1], color_counts=out[2], sources=out[3], kwidth=out[4], trailer=bool(out[5]))
+
+
+def format_float(v: float) -> str:
+    buf = ctypes.create_string_buffer(32)
+    n = lib().ksp_format_float(ctypes.c_float(v), buf)
+    return buf.raw[:n].decode()
 
 
 class Engine:

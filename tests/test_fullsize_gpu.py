@@ -1,0 +1,70 @@
+"""Full-size checks on BASELINE.json's bench workload (C2: 10k sources, ~5k hashes each),
+where the brute-force oracle is too slow for every pair: size-independent properties plus
+sampled pair checks against direct set intersection."""
+import numpy as np
+import pytest
+
+from kspider_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c2():
+    sk = synth.generate("C2")
+    dk = engine.DeviceBuffer.from_numpy(sk.keys)
+    e = engine.Engine(0)
+    e.build_blocks(dk.ptr.value, sk.offsets)
+    cap = 1 << 24
+    de = engine.DeviceBuffer(cap * 16)
+    return sk, dk, e, de, cap
+
+
+def _join(e, de, cap, t0, t1):
+    cnt = e.join(t0, t1, de.ptr.value, cap)
+    return np.sort(de.to_numpy(engine.EDGE_DTYPE, cnt), order=["source_1", "source_2"])
+
+
+def test_c2_properties_and_sampled_pairs(c2):
+    sk, dk, e, de, cap = c2
+    T = e.num_tiles
+    full = _join(e, de, cap, 0, T)
+    n = sk.n_sources
+    assert e.tile_pairs(0, T) == n * (n - 1) // 2
+    # ordering / range / uniqueness
+    assert (full["source_1"] < full["source_2"]).all() and full["source_2"].max() < n
+    key = full["source_1"].astype(np.int64) * n + full["source_2"]
+    assert (np.diff(key) > 0).all()
+    # shared <= min(n_a, n_b), never zero
+    sizes = sk.sizes
+    assert (full["shared"] > 0).all()
+    assert (full["shared"] <= np.minimum(sizes[full["source_1"]], sizes[full["source_2"]])).all()
+    # idempotence: a second join gives the same multiset
+    again = _join(e, de, cap, 0, T)
+    assert (again == full).all()
+    # partition invariance: joins over a split of the tile range unite to the same result
+    cut = [0, T // 3, T // 2 + 7, T]
+    parts = np.concatenate([_join(e, de, cap, cut[i], cut[i + 1]) for i in range(3)])
+    parts = np.sort(parts, order=["source_1", "source_2"])
+    assert (parts == full).all()
+    # sampled reported pairs and sampled random pairs against direct intersection
+    rng = np.random.default_rng(1)
+    for i in rng.choice(len(full), size=400, replace=False):
+        a, b, s = int(full["source_1"][i]), int(full["source_2"][i]), int(full["shared"][i])
+        assert np.intersect1d(sk.run(a), sk.run(b), assume_unique=True).size == s
+    present = set(key.tolist())
+    for _ in range(400):
+        a, b = sorted(rng.choice(n, size=2, replace=False).tolist())
+        s = np.intersect1d(sk.run(a), sk.run(b), assume_unique=True).size
+        assert (s > 0) == ((a * n + b) in present)
+    # every same-cluster pair shares something in this generator; check the checksum of
+    # per-source totals against an independent inverted-index count: sum_k C(m_k, 2)
+    uniq, counts = np.unique(sk.keys, return_counts=True)
+    assert int(full["shared"].sum()) == int((counts.astype(np.int64) * (counts - 1) // 2).sum())
+
+
+def test_overflow_is_reported_not_silent(c2):
+    sk, dk, e, de, cap = c2
+    with pytest.raises(engine.KspError) as ei:
+        e.join(0, e.num_tiles, de.ptr.value, 1000)
+    assert ei.value.code == engine.KSP_E_OVERFLOW
