@@ -240,6 +240,7 @@ struct JoinArgs {
     ksp_edge* out;
     u64 cap;
     unsigned long long* out_count;
+    u32 dbg;            // timing-only ablation switches (-DKSP_ABLATE builds + KSP_DEBUG_ABLATE; results are wrong when set)
 };
 
 __host__ __device__ inline u64 tile_row_start(u64 r, u64 nb) { return r * nb - r * (r - 1) / 2; }
@@ -268,12 +269,14 @@ __device__ inline uint4 load_a(const JoinArgs& a, u32 cbase, u32 pa, u32 ea, int
     uint4 k = make_uint4(INF_A, INF_A, INF_A, INF_A);
     if (cbase < ea) {   // wave-uniform
         k = reinterpret_cast<const uint4*>(a.brk)[(cbase >> 2) + lane];
-        const u32 p0 = cbase + 4u * lane;
-        // keys outside [pa, ea) belong to a neighbouring part: mask them
-        k.x = (p0 >= pa && p0 < ea) ? k.x : INF_A;
-        k.y = (p0 + 1 >= pa && p0 + 1 < ea) ? k.y : INF_A;
-        k.z = (p0 + 2 >= pa && p0 + 2 < ea) ? k.z : INF_A;
-        k.w = (p0 + 3 >= pa && p0 + 3 < ea) ? k.w : INF_A;
+        if (cbase < pa || cbase + WIN > ea) {   // wave-uniform: only the first / last chunk of a part
+            const u32 p0 = cbase + 4u * lane;
+            // keys outside [pa, ea) belong to a neighbouring part: mask them
+            k.x = (p0 >= pa && p0 < ea) ? k.x : INF_A;
+            k.y = (p0 + 1 >= pa && p0 + 1 < ea) ? k.y : INF_A;
+            k.z = (p0 + 2 >= pa && p0 + 2 < ea) ? k.z : INF_A;
+            k.w = (p0 + 3 >= pa && p0 + 3 < ea) ? k.w : INF_A;
+        }
     }
     return k;
 }
@@ -356,37 +359,50 @@ __device__ inline void add_masks(u32* S, uint4 mA, uint4 mB, u32 w, int lane) {
     }
 }
 
-// posting words (and weight) of up to 4 matches per lane, fetched one step ahead of use
+// One match per lane, posting words fetched one step ahead of their use.
 struct Pending {
-    u32 ia[4], ib[4], w[4];
-    bool h[4];
+    u32 ia, ib, w;
+    bool valid;
 };
-__device__ inline void pending_clear(Pending& q) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { q.h[j] = false; q.ia[j] = 0; q.ib[j] = 0; q.w[j] = 1; }
-}
+
+// Apply the pending matches of the wave to the tile.  Fast path (both keys held by a
+// single source of their block): one LDS atomic per lane, no loop.  Postings with 2..4
+// sources: nested loops with wave-uniform trip counts.  Larger postings: the whole wave
+// expands one match at a time from the 128-bit masks.
 __device__ inline void pending_apply(u32* S, const uint4* __restrict__ bigmask, const Pending& q, int lane) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool big = q.h[j] && ((q.ia[j] | q.ib[j]) >= BIG);   // either side has > 4 sources
-        if (q.h[j] && !big) add_inline(S, q.ia[j], q.ib[j], q.w[j]);
-        unsigned long long todo = __ballot(big);
-        while (todo) {   // wave-cooperative expansion, one match at a time
-            const int src = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const u32 ia = __builtin_amdgcn_readlane(q.ia[j], src);
-            const u32 ib = __builtin_amdgcn_readlane(q.ib[j], src);
-            const u32 w = __builtin_amdgcn_readlane(q.w[j], src);
-            add_masks<false>(S, posting_mask(ia, bigmask), posting_mask(ib, bigmask), w, lane);
+    const u32 both = q.ia | q.ib;
+    const bool simple = q.valid && both < 128u;
+    if (simple) atomicAdd(&S[(q.ia << 7) | q.ib], q.w);
+    const bool cx = q.valid && !simple;
+    if (__ballot(cx) == 0) return;
+    const bool small = cx && both < BIG;
+    const u32 nA = small ? (q.ia >> 29) + 1 : 0, nB = small ? (q.ib >> 29) + 1 : 0;
+    for (u32 x = 0; x < INLINE_MAX; ++x) {
+        if (__ballot(x < nA) == 0) break;
+        const u32 row = ((q.ia >> (7 * x)) & 127u) << 7;
+        for (u32 y = 0; y < INLINE_MAX; ++y) {
+            const bool act = x < nA && y < nB;
+            if (__ballot(act) == 0) break;
+            if (act) atomicAdd(&S[row | ((q.ib >> (7 * y)) & 127u)], q.w);
         }
+    }
+    unsigned long long todo = __ballot(cx && !small);
+    while (todo) {   // wave-cooperative expansion, one match at a time
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const u32 ia = __builtin_amdgcn_readlane(q.ia, src);
+        const u32 ib = __builtin_amdgcn_readlane(q.ib, src);
+        const u32 w = __builtin_amdgcn_readlane(q.w, src);
+        add_masks<false>(S, posting_mask(ia, bigmask), posting_mask(ib, bigmask), w, lane);
     }
 }
 
 template <bool W>
 __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
-    // 64 KB pair counters + 8 x 1.3 KB B windows: two workgroups per CU (160 KB LDS)
+    // 64 KB pair counters + 8 x (1.3 KB B window + 0.5 KB match queue): two workgroups per CU
     __shared__ u32 S[TB * TB];
     __shared__ Window win[JW];
+    __shared__ unsigned short mq[JW][WIN];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     u32 I, J;
@@ -444,7 +460,8 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
             uint4 B1 = load_b(a, cb + WIN, eb, lane);
             uint4 B2 = load_b(a, cb + 2 * WIN, eb, lane);
             Pending pend;
-            pending_clear(pend);
+            pend.ia = 0; pend.ib = 0; pend.w = 1; pend.valid = false;
+            unsigned short* q16 = mq[wv];
             bool newB = true;
             u32 s0 = 0, s1 = 0, s2 = 0;
             while (true) {
@@ -460,19 +477,58 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
                 }
                 // each lane looks its 4 A keys up in the 256-key B window
                 bool h0, h1, h2, h3;
+#ifdef KSP_ABLATE
+                if (a.dbg & 4) { asm volatile("" :: "v"(A0.x), "v"(A0.y), "v"(A0.z), "v"(A0.w)); goto advance; }
+#endif
+                {
                 const u32 p0 = window_find(wn, s0, s1, s2, A0.x, h0);
                 const u32 p1 = window_find(wn, s0, s1, s2, A0.y, h1);
                 const u32 p2 = window_find(wn, s0, s1, s2, A0.z, h2);
                 const u32 p3 = window_find(wn, s0, s1, s2, A0.w, h3);
+#ifdef KSP_ABLATE
+                if (a.dbg & 8) { h0 = h1 = h2 = h3 = false; asm volatile("" :: "v"(p0), "v"(p1), "v"(p2), "v"(p3)); }
+#endif
+                // compact the matches (A slot 0..255, B slot 0..255) into the wave's queue
+                u32 cnt = 0;
+                {
+                    const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+                    const u32 lo = 4u * lane;
+                    if (h0) q16[cnt + __builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, 0))] = (unsigned short)(((lo) << 8) | p0);
+                    cnt += (u32)__popcll(m0);
+                    if (h1) q16[cnt + __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, 0))] = (unsigned short)(((lo + 1) << 8) | p1);
+                    cnt += (u32)__popcll(m1);
+                    if (h2) q16[cnt + __builtin_amdgcn_mbcnt_hi((u32)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m2, 0))] = (unsigned short)(((lo + 2) << 8) | p2);
+                    cnt += (u32)__popcll(m2);
+                    if (h3) q16[cnt + __builtin_amdgcn_mbcnt_hi((u32)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m3, 0))] = (unsigned short)(((lo + 3) << 8) | p3);
+                    cnt += (u32)__popcll(m3);
+                }
                 // matches of the previous step: their posting words have arrived by now
+#ifdef KSP_ABLATE
+                if (!(a.dbg & 1))
+#endif
                 pending_apply(S, a.bigmask, pend, lane);
-                // fetch the posting words of this step's matches (consumed next step)
-                const u32 qa = ca + 4u * lane;
-                pend.h[0] = h0; pend.h[1] = h1; pend.h[2] = h2; pend.h[3] = h3;
-                if (h0) { pend.ia[0] = a.info[qa];     pend.ib[0] = a.info[cb + p0]; if (W) pend.w[0] = a.bw[qa]; }
-                if (h1) { pend.ia[1] = a.info[qa + 1]; pend.ib[1] = a.info[cb + p1]; if (W) pend.w[1] = a.bw[qa + 1]; }
-                if (h2) { pend.ia[2] = a.info[qa + 2]; pend.ib[2] = a.info[cb + p2]; if (W) pend.w[2] = a.bw[qa + 2]; }
-                if (h3) { pend.ia[3] = a.info[qa + 3]; pend.ib[3] = a.info[cb + p3]; if (W) pend.w[3] = a.bw[qa + 3]; }
+                pend.valid = false;
+#ifdef KSP_ABLATE
+                if (a.dbg & 2) cnt = 0;
+#endif
+                // fetch the posting words of this step's matches, 64 at a time (consumed next step)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                for (u32 base = 0; base < cnt; base += 64) {
+                    if (base) pending_apply(S, a.bigmask, pend, lane);   // rare: > 64 matches in one step
+                    const bool v = base + (u32)lane < cnt;
+                    pend.valid = v;
+                    if (v) {
+                        const u32 e = q16[base + lane];
+                        const u32 qa = ca + (e >> 8), qb = cb + (e & 255u);
+                        pend.ia = a.info[qa];
+                        pend.ib = a.info[qb];
+                        if (W) pend.w = a.bw[qa];
+                    }
+                }
+                }
+#ifdef KSP_ABLATE
+            advance:
+#endif
                 // advance whichever side ends first (both on a tie)
                 const bool afin = ca + WIN >= ea, bfin = cb + WIN >= eb;
                 const u32 aLast = afin ? INF_A : (u32)__builtin_amdgcn_readlane(A0.w, 63);
@@ -811,6 +867,8 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     a.out = d_edges;
     a.cap = capacity;
     a.out_count = e->count.as<unsigned long long>();
+    a.dbg = 0;
+    if (const char* dbg = std::getenv("KSP_DEBUG_ABLATE")) a.dbg = (u32)std::atoi(dbg);
     KSP_HIP(hipMemsetAsync(a.out_count, 0, 8, st));
     KSP_HIP(hipEventRecord(e->ev[2], st));
     dim3 grid((unsigned)(tile_end - tile_begin)), block(JW * 64);
