@@ -71,19 +71,111 @@ constexpr u32 INLINE_MAX = 4;         // sources whose 7-bit ids fit into the po
 // ------------------------------------------------------------------------------------
 
 // One workgroup per source: tag each entry with (block << 8 | local id) [and weight].
+// Weighted mode also records, per block, the largest per-source weight sum (the bound of
+// any pair counter that source takes part in).
 template <bool W>
 __global__ void k_tag(const u64* __restrict__ off, const u32* __restrict__ wts, u32* __restrict__ val32,
-                      u64* __restrict__ val64) {
+                      u64* __restrict__ val64, u32* __restrict__ blk_max) {
+    __shared__ unsigned long long acc;
     const u32 s = blockIdx.x;
     const u64 b = off[s], e = off[s + 1];
     const u32 tag = ((s / TB) << 8) | (s % TB);
+    if (W) { if (threadIdx.x == 0) acc = 0; __syncthreads(); }
+    unsigned long long part = 0;
     for (u64 i = b + threadIdx.x; i < e; i += blockDim.x) {
-        if (W) val64[i] = ((u64)wts[i] << 32) | tag;
+        if (W) { const u32 w = wts[i]; part += w; val64[i] = ((u64)w << 32) | tag; }
         else val32[i] = tag;
+    }
+    if (W) {
+        if (part) atomicAdd(&acc, part);
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&blk_max[s / TB], (u32)(acc > 0xFFFFFFFFull ? 0xFFFFFFFFull : acc));
     }
 }
 
 template <class V> __device__ inline u32 tag_of(V v) { return (u32)v; }
+
+// The global sort only looks at the top 32 significant bits of the keys (4 radix passes
+// instead of up to 8).  Entries whose keys agree in those bits are adjacent afterwards;
+// almost always they are copies of ONE key (the same hash in several sources).  Where two or
+// more distinct keys share the bits, this kernel orders that short run by the full key so
+// that equal keys become adjacent (ranks only have to be consistent, not numerically
+// ordered).  Runs longer than MAX_FIX raise *overflow and the caller falls back to a
+// full-width sort.
+constexpr u32 MAX_FIX = 2048;
+// pass 1 (streaming): positions where two neighbours share the sorted prefix but differ as
+// full keys go to a work list (rare: ~D^2 / 2^33 of D distinct keys).
+__global__ __launch_bounds__(1024) void k_find_mixed(const u64* __restrict__ keys, u64 n, int shift,
+                                                     u32* __restrict__ list, u32* __restrict__ count, u32 cap,
+                                                     u32* __restrict__ overflow) {
+    // 4096 entries per workgroup; hits are compacted in LDS so that the global counter sees
+    // one atomic per workgroup (a single word saturates at ~88 atomics/us on this chip)
+    __shared__ u32 local[4096];
+    __shared__ u32 nlocal, base;
+    if (threadIdx.x == 0) nlocal = 0;
+    __syncthreads();
+    const u64 e0 = (u64)blockIdx.x * 4096 + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const u64 e = e0 + (u64)r * 1024;
+        if (e > 0 && e < n) {
+            const u64 a = keys[e - 1], b = keys[e];
+            if (a != b && (a >> shift) == (b >> shift)) local[atomicAdd(&nlocal, 1u)] = (u32)e;
+        }
+    }
+    __syncthreads();
+    const u32 m = nlocal;
+    if (m == 0) return;
+    if (threadIdx.x == 0) base = atomicAdd(count, m);
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < m; i += 1024) {
+        if (base + i < cap) list[base + i] = local[i];
+        else *overflow = 1;
+    }
+}
+// pass 2 (work list, read-only): keep only the first listed position of every run — the one
+// with no differing neighbour pair between the run's start and itself; list[i] |= DROP otherwise.
+constexpr u32 DROP = 0x80000000u;
+__global__ void k_mark_first(const u64* __restrict__ keys, int shift, u32* __restrict__ list,
+                             const u32* __restrict__ count, u32 cap, u32* __restrict__ overflow) {
+    const u32 m = min(*count, cap);
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const u64 p = list[i];
+        const u64 h0 = keys[p] >> shift;
+        bool first = true;
+        for (u64 s = p - 1; s > 0 && (keys[s - 1] >> shift) == h0; --s) {
+            if (keys[s - 1] != keys[s]) { first = false; break; }
+            if (p - s > MAX_FIX) { *overflow = 1; first = false; break; }
+        }
+        if (!first) list[i] = (u32)p | DROP;
+    }
+}
+// pass 3: one thread per kept position orders its run by the full key (runs are disjoint).
+template <class V>
+__global__ void k_fix_runs(u64* __restrict__ keys, V* __restrict__ vals, u64 n, int shift,
+                           const u32* __restrict__ list, const u32* __restrict__ count, u32 cap,
+                           u32* __restrict__ overflow) {
+    const u32 m = min(*count, cap);
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        if (list[i] & DROP) continue;
+        const u64 p = list[i];
+        const u64 h0 = keys[p] >> shift;
+        u64 s = p;
+        while (s > 0 && (keys[s - 1] >> shift) == h0) --s;   // <= MAX_FIX steps (checked by k_mark_first)
+        u64 end = p + 1;
+        while (end < n && (keys[end] >> shift) == h0 && end - s <= MAX_FIX) ++end;
+        if (end - s > MAX_FIX) { *overflow = 1; continue; }
+        // stable insertion sort of the run by full key (keeps ascending source order inside a key)
+        for (u64 a = s + 1; a < end; ++a) {
+            const u64 k = keys[a];
+            const V v = vals[a];
+            u64 j = a;
+            while (j > s && keys[j - 1] > k) { keys[j] = keys[j - 1]; vals[j] = vals[j - 1]; --j; }
+            keys[j] = k;
+            vals[j] = v;
+        }
+    }
+}
 
 // After the global sort by key: flag[e] = 1 where a new distinct key starts (0 at e = 0),
 // so that inclusive_scan(flag) is the key's dense rank — an exact, order-preserving
@@ -234,6 +326,7 @@ struct JoinArgs {
     const u32* blk_raw; // nb + 1: unpadded distinct-key offsets (counts)
     const u32* blk_pos; // nb + 1: start of every block list in the padded layout
     const u32* part;    // nb * (NP + 1): positions in the padded layout
+    const u32* blk_max; // nb: largest per-source k-mer count (weight sum) in the block
     u32 nb;
     u32 n_sources;
     u64 tile_begin;
@@ -314,13 +407,24 @@ __device__ inline u32 window_find(const Window& w, u32 s0, u32 s1, u32 s2, u32 k
 }
 
 // ---- applying a match to the LDS tile of pair counters -------------------------------
+// C16: two 16-bit counters per LDS word (row-major, even column in the low half).  Exact
+// whenever every counter of the tile stays < 2^16, which the kernel guarantees by only
+// taking tiles where one of the two blocks holds no source with >= 65536 k-mers
+// (shared <= min(n_a, n_b)).  Halves the tile to 32 KB -> 3 workgroups per CU.
+template <bool C16>
+__device__ inline void s_add(u32* S, u32 idx, u32 w) {
+    if (C16) atomicAdd(&S[idx >> 1], w << ((idx & 1u) * 16u));
+    else atomicAdd(&S[idx], w);
+}
+
 // Small postings (<= 4 sources, inline in the posting word): the lane adds its own
 // cross product.  No memory traffic besides the LDS atomics.
+template <bool C16>
 __device__ inline void add_inline(u32* S, u32 ia, u32 ib, u32 w) {
     const u32 nA = (ia >> 29) + 1, nB = (ib >> 29) + 1;
     for (u32 x = 0; x < nA; ++x) {
         const u32 row = ((ia >> (7 * x)) & 127u) * TB;
-        for (u32 y = 0; y < nB; ++y) atomicAdd(&S[row + ((ib >> (7 * y)) & 127u)], w);
+        for (u32 y = 0; y < nB; ++y) s_add<C16>(S, row + ((ib >> (7 * y)) & 127u), w);
     }
 }
 
@@ -341,7 +445,7 @@ __device__ inline uint4 posting_mask(u32 inf, const uint4* __restrict__ bigmask)
 // (lane, lane + 64) of the tile, rows come from a scalar walk over the bits of mask A:
 // every LDS atomic touches 64 consecutive counters (conflict free).
 // SELF: both postings are the same key of the same block -> only pairs row < column.
-template <bool SELF>
+template <bool SELF, bool C16>
 __device__ inline void add_masks(u32* S, uint4 mA, uint4 mB, u32 w, int lane) {
     const u32 bw0 = lane < 32 ? mB.x : mB.y, bw1 = lane < 32 ? mB.z : mB.w;
     const bool c0 = (bw0 >> (lane & 31)) & 1u, c1 = (bw1 >> (lane & 31)) & 1u;
@@ -352,9 +456,9 @@ __device__ inline void add_masks(u32* S, uint4 mA, uint4 mB, u32 w, int lane) {
         while (word) {
             const u32 r = 32u * k + (u32)__builtin_ctz(word);
             word &= word - 1;
-            u32* row = S + r * TB;
-            if (c0 && (!SELF || (u32)lane > r)) atomicAdd(&row[lane], w);
-            if (c1 && (!SELF || (u32)lane + 64u > r)) atomicAdd(&row[lane + 64], w);
+            const u32 row = r * TB;
+            if (c0 && (!SELF || (u32)lane > r)) s_add<C16>(S, row + lane, w);
+            if (c1 && (!SELF || (u32)lane + 64u > r)) s_add<C16>(S, row + lane + 64, w);
         }
     }
 }
@@ -369,10 +473,11 @@ struct Pending {
 // single source of their block): one LDS atomic per lane, no loop.  Postings with 2..4
 // sources: nested loops with wave-uniform trip counts.  Larger postings: the whole wave
 // expands one match at a time from the 128-bit masks.
+template <bool C16>
 __device__ inline void pending_apply(u32* S, const uint4* __restrict__ bigmask, const Pending& q, int lane) {
     const u32 both = q.ia | q.ib;
     const bool simple = q.valid && both < 128u;
-    if (simple) atomicAdd(&S[(q.ia << 7) | q.ib], q.w);
+    if (simple) s_add<C16>(S, (q.ia << 7) | q.ib, q.w);
     const bool cx = q.valid && !simple;
     if (__ballot(cx) == 0) return;
     const bool small = cx && both < BIG;
@@ -383,7 +488,7 @@ __device__ inline void pending_apply(u32* S, const uint4* __restrict__ bigmask, 
         for (u32 y = 0; y < INLINE_MAX; ++y) {
             const bool act = x < nA && y < nB;
             if (__ballot(act) == 0) break;
-            if (act) atomicAdd(&S[row | ((q.ib >> (7 * y)) & 127u)], q.w);
+            if (act) s_add<C16>(S, row | ((q.ib >> (7 * y)) & 127u), q.w);
         }
     }
     unsigned long long todo = __ballot(cx && !small);
@@ -393,22 +498,25 @@ __device__ inline void pending_apply(u32* S, const uint4* __restrict__ bigmask, 
         const u32 ia = __builtin_amdgcn_readlane(q.ia, src);
         const u32 ib = __builtin_amdgcn_readlane(q.ib, src);
         const u32 w = __builtin_amdgcn_readlane(q.w, src);
-        add_masks<false>(S, posting_mask(ia, bigmask), posting_mask(ib, bigmask), w, lane);
+        add_masks<false, C16>(S, posting_mask(ia, bigmask), posting_mask(ib, bigmask), w, lane);
     }
 }
 
-template <bool W>
+template <bool W, bool C16>
 __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
-    // 64 KB pair counters + 8 x (1.3 KB B window + 0.5 KB match queue): two workgroups per CU
-    __shared__ u32 S[TB * TB];
+    // pair counters (32 KB packed 16-bit / 64 KB 32-bit) + 8 x (1.3 KB B window + 0.5 KB match
+    // queue): three (C16) or two workgroups per CU
+    __shared__ u32 S[C16 ? TB * TB / 2 : TB * TB];
     __shared__ Window win[JW];
     __shared__ unsigned short mq[JW][WIN];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     u32 I, J;
     tile_decode(a.tile_begin + blockIdx.x, a.nb, I, J);
+    // 16-bit counters are exact iff one of the two blocks has no source with >= 2^16 k-mers
+    if ((min(a.blk_max[I], a.blk_max[J]) < 65536u) != C16) return;
 
-    for (int i = tid; i < TB * TB; i += JW * 64) S[i] = 0;
+    for (int i = tid; i < (C16 ? TB * TB / 2 : TB * TB); i += JW * 64) S[i] = 0;
     __syncthreads();
 
     if (I == J) {
@@ -425,7 +533,7 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
                 const u32 n = (inf >> 29) + 1;
                 for (u32 x = 0; x + 1 < n; ++x) {
                     const u32 row = ((inf >> (7 * x)) & 127u) * TB;
-                    for (u32 y = x + 1; y < n; ++y) atomicAdd(&S[row + ((inf >> (7 * y)) & 127u)], w);
+                    for (u32 y = x + 1; y < n; ++y) s_add<C16>(S, row + ((inf >> (7 * y)) & 127u), w);
                 }
             }
             unsigned long long todo = __ballot(big);
@@ -435,7 +543,7 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
                 const u32 si = __builtin_amdgcn_readlane(inf, src);
                 const u32 sw = __builtin_amdgcn_readlane(w, src);
                 const uint4 m = posting_mask(si, a.bigmask);
-                add_masks<true>(S, m, m, sw, lane);
+                add_masks<true, C16>(S, m, m, sw, lane);
             }
         }
     } else {
@@ -506,7 +614,7 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
 #ifdef KSP_ABLATE
                 if (!(a.dbg & 1))
 #endif
-                pending_apply(S, a.bigmask, pend, lane);
+                pending_apply<C16>(S, a.bigmask, pend, lane);
                 pend.valid = false;
 #ifdef KSP_ABLATE
                 if (a.dbg & 2) cnt = 0;
@@ -514,7 +622,7 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
                 // fetch the posting words of this step's matches, 64 at a time (consumed next step)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 for (u32 base = 0; base < cnt; base += 64) {
-                    if (base) pending_apply(S, a.bigmask, pend, lane);   // rare: > 64 matches in one step
+                    if (base) pending_apply<C16>(S, a.bigmask, pend, lane);   // rare: > 64 matches in one step
                     const bool v = base + (u32)lane < cnt;
                     pend.valid = v;
                     if (v) {
@@ -547,7 +655,7 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
                     B2 = load_b(a, cb + 2 * WIN, eb, lane);
                 }
             }
-            pending_apply(S, a.bigmask, pend, lane);
+            pending_apply<C16>(S, a.bigmask, pend, lane);
         }
     }
     __syncthreads();
@@ -556,7 +664,7 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
     const u32 gi0 = I * TB, gj0 = J * TB;
     for (int base = 0; base < TB * TB; base += JW * 64) {
         int idx = base + tid;
-        u32 v = S[idx];
+        u32 v = C16 ? ((S[idx >> 1] >> ((idx & 1) * 16)) & 0xFFFFu) : S[idx];
         bool nz = v != 0;
         unsigned long long mask = __ballot(nz);
         if (mask == 0) continue;
@@ -603,11 +711,14 @@ struct ksp_engine {
     u64 n_entries = 0;
     bool weighted = false;
     bool built = false;
+    bool full_sort = false;       // keys defeat the 32-bit prefix sort: use all bits
+    bool need32 = false;          // some tile pairs two blocks that both hold a source with >= 2^16 k-mers
     int key_bits = 64;
     std::vector<u64> h_off;
     std::vector<u32> h_blk_off;   // distinct-key offsets of the block lists (host copy)
+    std::vector<u32> h_blk_max;   // per block: largest per-source k-mer count / weight sum
     // workspace
-    ksp::Buf d_off, KA, KB, VA, VB, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, part, scalars, count;
+    ksp::Buf d_off, KA, KB, VA, VB, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, blk_max, part, scalars, count;
     unsigned long long* h_count = nullptr;   // pinned
     u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -636,6 +747,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if ((rc = e->blk_raw.ensure(((size_t)nb + 2) * 4))) return rc;
     if ((rc = e->blk_pos.ensure(((size_t)nb + 2) * 4))) return rc;
     if ((rc = e->part.ensure(((size_t)nb + 1) * (NP + 1) * 4))) return rc;
+    if ((rc = e->blk_max.ensure(((size_t)nb + 2) * 4))) return rc;
     if ((rc = e->scalars.ensure(64))) return rc;
 
     u64* KA = e->KA.as<u64>();
@@ -664,13 +776,33 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     int bbits = 1;
     while ((1u << bbits) < nb) ++bbits;
 
+    if (W) KSP_HIP(hipMemsetAsync(e->blk_max.p, 0, ((size_t)nb + 1) * 4, st));
     hipLaunchKernelGGL((k_tag<W>), dim3(N), dim3(256), 0, st, d_off, d_w, W ? nullptr : (u32*)VA,
-                       W ? (u64*)VA : nullptr);
-    // sort 1: all entries by key (payload = tag [+weight]):  d_keys,VA -> KA,VB
+                       W ? (u64*)VA : nullptr, e->blk_max.as<u32>());
+    // sort 1: all entries by the top 32 significant key bits (payload = tag [+weight]):
+    // d_keys,VA -> KA,VB; then order the rare mixed runs by the full key (k_fix_runs)
+    // (rocPRIM 4.2 / ROCm 7.2 mis-sorts 64-bit keys on any bit range [b > 0, 64) below ~1M items —
+    //  found with a stand-alone sweep on MI355X; ranges ending below bit 64 are fine — so keys
+    //  that use all 64 bits take the full-width sort.)
+    const int shift = (e->full_sort || kbits >= 64) ? 0 : std::max(0, kbits - 32);
+    u32* d_ovf = (u32*)(scal + 4);   // set by k_fix_runs when a run is too long; checked at the end of the build
+    KSP_HIP(hipMemsetAsync(d_ovf, 0, 8, st));
     tb = 0;
-    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_keys, KA, VA, VB, n, 0, kbits, st));
+    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_keys, KA, VA, VB, n, shift, kbits, st));
     if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, d_keys, KA, VA, VB, n, 0, kbits, st));
+    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, d_keys, KA, VA, VB, n, shift, kbits, st));
+    if (shift > 0) {
+        // KB is free until the rank scan: use it for the work list of mixed runs
+        u32* fixlist = (u32*)e->KB.p;
+        const u32 fixcap = (u32)std::min<u64>(2 * n, 0x7FFFFFFFull);   // positions are < 2^30 (DROP bit is free)
+        u32* d_cnt = (u32*)(scal + 5);
+        KSP_HIP(hipMemsetAsync(d_cnt, 0, 8, st));
+        hipLaunchKernelGGL(k_find_mixed, dim3(grid_for(n, 4096)), dim3(1024), 0, st, KA, n, shift, fixlist, d_cnt,
+                           fixcap, d_ovf);
+        hipLaunchKernelGGL(k_mark_first, dim3(4096), dim3(64), 0, st, KA, shift, fixlist, d_cnt, fixcap, d_ovf);
+        hipLaunchKernelGGL((k_fix_runs<V>), dim3(4096), dim3(64), 0, st, KA, VB, n, shift, fixlist, d_cnt, fixcap,
+                           d_ovf);
+    }
     // dense rank of every key: exact 32-bit stand-in for the hash
     u32* kflag = (u32*)e->KB.p;            // n
     u32* krank = (u32*)e->KB.p + (n + 2);  // n
@@ -757,7 +889,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->tmp, &e->bkeys, &e->info,
-                        &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->part, &e->scalars, &e->count};
+                        &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
@@ -783,6 +915,7 @@ int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_
     e->weighted = d_weights != nullptr;
     e->key_bits = key_bits;
     e->h_off.assign(h_offsets, h_offsets + n_sources + 1);
+    if (std::getenv("KSP_FULL_SORT")) e->full_sort = true;   // diagnostic: sort on all key bits
     e->st = ksp_stats{};
     e->st.n_sources = n_sources;
     e->st.n_entries = n;
@@ -798,13 +931,36 @@ int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_
     if ((rc = e->d_off.ensure(((size_t)n_sources + 1) * 8))) return rc;
     KSP_HIP(hipEventRecord(e->ev[0], st));
     KSP_HIP(hipMemcpyAsync(e->d_off.p, h_offsets, ((size_t)n_sources + 1) * 8, hipMemcpyHostToDevice, st));
-    rc = e->weighted ? build_impl<true>(e, d_keys, d_weights, st) : build_impl<false>(e, d_keys, d_weights, st);
-    if (rc) return rc;
-    KSP_HIP(hipEventRecord(e->ev[1], st));
-    KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 8, hipMemcpyDeviceToHost, st));
-    KSP_HIP(hipStreamSynchronize(st));
+    if ((rc = e->blk_max.ensure(((size_t)e->nb + 2) * 4))) return rc;
+    e->h_blk_max.assign((size_t)e->nb + 1, 0);
+    if (!e->weighted) {   // raw hashes: a source's bound is its k-mer count
+        for (u32 s = 0; s < n_sources; ++s) {
+            u64 c = h_offsets[s + 1] - h_offsets[s];
+            u32& m = e->h_blk_max[s / TB];
+            m = std::max<u32>(m, (u32)std::min<u64>(c, 0xFFFFFFFFull));
+        }
+        KSP_HIP(hipMemcpyAsync(e->blk_max.p, e->h_blk_max.data(), ((size_t)e->nb + 1) * 4, hipMemcpyHostToDevice, st));
+    }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        rc = e->weighted ? build_impl<true>(e, d_keys, d_weights, st) : build_impl<false>(e, d_keys, d_weights, st);
+        if (rc) return rc;
+        KSP_HIP(hipEventRecord(e->ev[1], st));
+        KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 32, hipMemcpyDeviceToHost, st));
+        KSP_HIP(hipStreamSynchronize(st));
+        if ((u32)e->h_scal[4] == 0) break;
+        // pathological key distribution (thousands of distinct keys share their top 32 bits):
+        // redo with a full-width sort and remember it for later builds on this engine
+        e->full_sort = true;
+    }
     KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
     e->st.n_block_keys = e->h_scal[1];
+    if (e->weighted)
+        KSP_HIP(hipMemcpy(e->h_blk_max.data(), e->blk_max.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
+    {
+        u32 big_blocks = 0;
+        for (u32 b = 0; b < e->nb; ++b) big_blocks += e->h_blk_max[b] >= 65536u;
+        e->need32 = big_blocks >= 1;   // a big block pairs with itself (diagonal tile) at least
+    }
     e->h_blk_off.resize((size_t)e->nb + 1);
     KSP_HIP(hipMemcpy(e->h_blk_off.data(), e->blk_raw.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
     e->st.key_bits = e->key_bits;
@@ -872,8 +1028,14 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     KSP_HIP(hipMemsetAsync(a.out_count, 0, 8, st));
     KSP_HIP(hipEventRecord(e->ev[2], st));
     dim3 grid((unsigned)(tile_end - tile_begin)), block(JW * 64);
-    if (e->weighted) hipLaunchKernelGGL((k_join<true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_join<false>), grid, block, 0, st, a);
+    a.blk_max = e->blk_max.as<u32>();
+    // packed 16-bit counters wherever they are exact; 32-bit counters for the other tiles
+    if (e->weighted) hipLaunchKernelGGL((k_join<true, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_join<false, true>), grid, block, 0, st, a);
+    if (e->need32) {
+        if (e->weighted) hipLaunchKernelGGL((k_join<true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_join<false, false>), grid, block, 0, st, a);
+    }
     KSP_HIP(hipGetLastError());
     KSP_HIP(hipEventRecord(e->ev[3], st));
     KSP_HIP(hipMemcpyAsync(e->h_count, a.out_count, 8, hipMemcpyDeviceToHost, st));

@@ -58,3 +58,58 @@ def test_identical_sketches_dense_overlap(oracle_lib):
     sk = synth.from_runs(runs)
     edges, _ = _check(sk, oracle_lib)
     assert len(edges) == 140 * 139 // 2
+
+
+def test_huge_sketches_use_32bit_counters(oracle_lib):
+    """Pairs of sources with >= 2^16 k-mers can share >= 2^16 of them: those tiles must take
+    the 32-bit counter kernel (the packed 16-bit tile would overflow)."""
+    rng = np.random.default_rng(11)
+    big = np.unique(rng.integers(1, 1 << 60, size=90000, dtype=np.uint64))
+    runs = []
+    for s in range(300):
+        if s in (3, 7, 140, 290):          # two in block 0, one in block 1, one in block 2
+            runs.append(big[: 70000 + 1000 * (s % 5)])
+        else:
+            own = rng.integers(1, 1 << 60, size=200, dtype=np.uint64)
+            runs.append(np.concatenate([own, big[rng.integers(0, 90000, size=50)]]))
+    sk = synth.from_runs(runs)
+    edges, st = _check(sk, oracle_lib)
+    assert int(edges["shared"].max()) >= 70000
+
+
+def test_weighted_sums_beyond_16_bits(oracle_lib):
+    """Colour weights whose per-source sums exceed 2^16 (32-bit counter kernel in weighted mode)."""
+    n = 260
+    keys, wts, offs = [], [], [0]
+    for s in range(n):
+        k = np.arange(1, 41, dtype=np.uint64) if s % 2 == 0 else np.arange(20, 61, dtype=np.uint64)
+        keys.append(k)
+        wts.append((k * 100).astype(np.uint32))      # sums ~ 80k-160k per source
+        offs.append(offs[-1] + k.size)
+    keys = np.concatenate(keys); wts = np.concatenate(wts); offs = np.array(offs, dtype=np.uint64)
+    edges, st = engine.pairwise_host(keys, offs, wts)
+    want = {}
+    for a in range(n):
+        for b in range(a + 1, n):
+            ka = set(range(1, 41)) if a % 2 == 0 else set(range(20, 61))
+            kb = set(range(1, 41)) if b % 2 == 0 else set(range(20, 61))
+            want[(a, b)] = sum(100 * x for x in ka & kb)
+    got = {(int(e["source_1"]), int(e["source_2"])): int(e["shared"]) for e in edges}
+    assert got == want and max(want.values()) > 65535
+
+
+def test_keys_sharing_their_top_bits(oracle_lib):
+    """Distinct keys that agree in their top 32 significant bits: the prefix sort's fix-up path,
+    and (thousands of them) the fall-back to a full-width sort."""
+    rng = np.random.default_rng(12)
+    base = np.uint64(0xABCDEF0100000000)
+    # small mixed runs: pairs/triples of keys differing only in low bits, spread over sources
+    lows = rng.integers(0, 1 << 20, size=(400, 3), dtype=np.uint64)
+    his = (rng.integers(1, 1 << 30, size=400, dtype=np.uint64) << np.uint64(32))
+    pool = (his[:, None] | lows).ravel()
+    runs = [np.unique(pool[rng.integers(0, pool.size, size=150)]) for _ in range(200)]
+    _check(synth.from_runs(runs), oracle_lib)
+    # one giant run: 5000 distinct keys with identical top 32 bits -> overflow -> full sort
+    giant = base | rng.integers(0, 1 << 31, size=5000, dtype=np.uint64)
+    runs = [np.unique(giant[rng.integers(0, giant.size, size=300)]) for _ in range(150)]
+    _check(synth.from_runs(runs), oracle_lib)
