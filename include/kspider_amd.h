@@ -103,6 +103,18 @@ void ksp_free(void* p);
  * PREFIX_kSpider_pairwise.tsv.  Device = $KSPIDER_DEVICE (default 0).                  */
 int kspider_pairwise(const char* index_prefix, int user_threads);
 
+/* ---- direct sketch inputs ----------------------------------
+ * kspider_pairwise_sigs: sourmash signatures (every .sig file of DIR) -> pairwise TSVs in one go; what
+ *   kSpider::sourmash_sigs_indexing(sigs_dir, kSize) (include/kSpider.hpp:18,
+ *   src/sourmash_indexing.cpp:52) followed by kSpider::pairwise() computes, with the same group-ID
+ *   assignment (glob order), first signature with ksize == kSize, PREFIX.namesMap format.
+ * kspider_pairwise_bins: sketches stored as phmap::flat_hash_set<uint64_t> dumps, every .bin file of DIR (the
+ *   input format of kSpider::bins_indexing, src/bins_indexing.cpp:98-182).
+ * out_prefix NULL/"" -> basename(DIR) in the current directory, as the reference does.
+ * Writes PREFIX.namesMap, PREFIX_kSpider_seqToKmersNo.tsv, PREFIX_kSpider_pairwise.tsv.        */
+int kspider_pairwise_sigs(const char* sigs_dir, int kSize, const char* out_prefix, int user_threads);
+int kspider_pairwise_bins(const char* bins_dir, const char* out_prefix, int user_threads);
+
 /* ---- host-only diagnostics (no GPU needed) -------------------------------------------
  * ksp_index_info: parse the three index files and report what the reader detected:
  * out[0] colours, out[1] groups, out[2] colour-count entries, out[3] sum of sources over

@@ -8,6 +8,6 @@ Host-side mirror of the reference interface for this one path:
 The compute lives in kspider_amd/lib/libkspider_amd.so (hand-written HIP, gfx950); nothing here
 falls back to the CPU.
 """
-from .engine import pairwise  # noqa: F401
+from .engine import pairwise, pairwise_bins, pairwise_sigs  # noqa: F401
 
-__all__ = ["pairwise"]
+__all__ = ["pairwise", "pairwise_sigs", "pairwise_bins"]

@@ -105,7 +105,7 @@ int try_single(const FileBuf& f, size_t slot_bytes, Layout lay, Fn fn) {
     int clone = 0;
     if (!parse_table(f.b, pos, slot_bytes, lay, &clone, fn)) return 0;
     if (pos != f.b.size()) return 0;
-    return 1 + clone;
+    return 1 + 2 * clone;   // matching cloned control bytes outweigh the kWidth-16 preference
 }
 
 }  // namespace
@@ -138,7 +138,7 @@ void load_index(const std::string& prefix, IndexData& out) {
             ok = ok && pos == fs.b.size();
         }
         if (!ok) continue;
-        int score = 1 + s1 + s2 + (clone > 0 ? 2 : 0) + (kLayouts[li].kwidth == 16 ? 1 : 0);
+        int score = 1 + s1 + s2 + (clone > 0 ? 2 : 0) + (kLayouts[li].kwidth == 16 ? 1 : 0);   // clone bytes decide ties
         if (score > best_score) { best_score = score; best = li; }
     }
     if (best < 0)
@@ -192,6 +192,23 @@ void load_index(const std::string& prefix, IndexData& out) {
             }
         }
     }
+}
+
+void load_u64_set(const std::string& path, std::vector<uint64_t>& out) {
+    FileBuf f(path);
+    int best = -1, best_score = 0;
+    for (int li = 0; li < 4; ++li) {
+        int sc = try_single(f, 8, kLayouts[li], [](const unsigned char*) {});
+        if (sc) sc += kLayouts[li].kwidth == 16 ? 1 : 0;
+        if (sc > best_score) { best_score = sc; best = li; }
+    }
+    if (best < 0) throw std::runtime_error("kspider_amd: " + path + " is not a phmap flat_hash_set<uint64_t> dump");
+    out.clear();
+    try_single(f, 8, kLayouts[best], [&](const unsigned char* s) {
+        uint64_t v;
+        std::memcpy(&v, s, 8);
+        out.push_back(v);
+    });
 }
 
 void write_seq_to_kmers(const std::string& prefix, const IndexData& ix) {

@@ -37,6 +37,10 @@ struct EdgeRow {
 void write_pairwise_tsv(const std::string& prefix, const std::vector<EdgeRow>& rows,
                         const std::unordered_map<uint32_t, uint32_t>& kmer_count, int threads);
 
+// One phmap::flat_hash_set<uint64_t> dump (a sketch ".bin": sigs_to_bins.cpp:113-136,
+// src/bins_indexing.cpp:178-180) -> its hashes in slot order.
+void load_u64_set(const std::string& path, std::vector<uint64_t>& out);
+
 // "%g"-style text of a float exactly as `std::ostream << float` prints it.
 int format_float(char* buf, float v);
 

@@ -24,6 +24,7 @@ ABI_SYMBOLS = [
     "ksp_engine_build_blocks", "ksp_engine_num_tiles", "ksp_engine_tile_pairs", "ksp_engine_join",
     "ksp_engine_get_stats", "ksp_device_malloc", "ksp_device_free", "ksp_memcpy_h2d", "ksp_memcpy_d2h",
     "ksp_pairwise_host", "ksp_free", "kspider_pairwise", "ksp_index_info", "ksp_format_float",
+    "kspider_pairwise_sigs", "kspider_pairwise_bins",
 ]
 
 
@@ -82,6 +83,8 @@ def lib():
         L.kspider_pairwise.argtypes = [ctypes.c_char_p, ctypes.c_int]
         L.ksp_index_info.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
         L.ksp_format_float.argtypes = [ctypes.c_float, ctypes.c_char_p]
+        L.kspider_pairwise_sigs.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L.kspider_pairwise_bins.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -119,6 +122,18 @@ def pairwise_host(keys: np.ndarray, offsets: np.ndarray, weights: np.ndarray | N
 def pairwise(index_prefix: str, user_threads: int = 1) -> None:
     """kSpider::pairwise(index_prefix, user_threads) through the C ABI (reference: kSpider.hpp:11)."""
     _check(lib().kspider_pairwise(os.fsencode(index_prefix), int(user_threads)))
+
+
+def pairwise_sigs(sigs_dir: str, kSize: int, out_prefix: str | None = None, user_threads: int = 1) -> None:
+    """sourmash signatures -> pairwise TSVs (= sourmash_sigs_indexing(sigs_dir, kSize) + pairwise())."""
+    _check(lib().kspider_pairwise_sigs(os.fsencode(sigs_dir), int(kSize),
+                                       os.fsencode(out_prefix) if out_prefix else None, int(user_threads)))
+
+
+def pairwise_bins(bins_dir: str, out_prefix: str | None = None, user_threads: int = 1) -> None:
+    """phmap flat_hash_set<uint64> sketch dumps (*.bin) -> pairwise TSVs."""
+    _check(lib().kspider_pairwise_bins(os.fsencode(bins_dir), os.fsencode(out_prefix) if out_prefix else None,
+                                       int(user_threads)))
 
 
 def index_info(index_prefix: str) -> dict:

@@ -121,6 +121,15 @@ def write_index(prefix: str, color_off, sources, color_w, group_ids, kmer_counts
                                     ctypes.c_uint64(slot_seed)))
 
 
+def write_bin_sketch(path: str, hashes: np.ndarray, kwidth: int = 16, trailer: bool = True, slot_seed: int = 99):
+    """One sketch as a phmap flat_hash_set<uint64_t> dump (.bin)."""
+    h = np.ascontiguousarray(hashes, dtype=np.uint64)
+    rc = lib().oracle_write_bin_sketch(path.encode(), _p(h, ctypes.c_uint64), ctypes.c_uint64(h.size),
+                                       ctypes.c_int(kwidth), ctypes.c_int(int(trailer)), ctypes.c_uint64(slot_seed))
+    if rc != 0:
+        raise RuntimeError("write_bin_sketch failed")
+
+
 def index_from_sketches(prefix: str, keys, offsets, group_ids=None, **kw):
     """Sketches -> colour index files (what `kSpider index` hands to `kSpider pairwise`)."""
     color_off, sources, color_w = build_colors(keys, offsets, group_ids)

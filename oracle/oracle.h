@@ -55,6 +55,10 @@ int oracle_write_index(const char* index_prefix, const uint32_t* color_off, cons
                        const uint32_t* kmer_counts, uint32_t n_sources, int kwidth, int trailer,
                        uint64_t slot_seed);
 
+/* One sketch as a phmap::flat_hash_set<uint64_t> dump (".bin", src/bins_indexing.cpp:178-180). */
+int oracle_write_bin_sketch(const char* path, const uint64_t* hashes, uint64_t n, int kwidth, int trailer,
+                            uint64_t slot_seed);
+
 /* Brute force, the semantics of test/generate_golden_files.py:40-49:
  * shared = |A ∩ B| for every a < b, non-zero pairs only, sorted by (a, b).
  * IDs are dense indices 0..n-1.  Returns the number of edges (or -1 if the

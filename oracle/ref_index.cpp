@@ -213,6 +213,23 @@ int oracle_write_index(const char* index_prefix, const uint32_t* color_off, cons
     }
 }
 
+// One sketch as a phmap::flat_hash_set<uint64_t> dump (the ".bin" files of
+// sigs_to_bins.cpp:113-136 / src/bins_indexing.cpp:178-180), restated layout.
+int oracle_write_bin_sketch(const char* path, const uint64_t* hashes, uint64_t n, int kwidth, int trailer,
+                            uint64_t slot_seed) {
+    try {
+        std::ofstream f(path, std::ios::binary);
+        if (!f) throw std::runtime_error(std::string("cannot write ") + path);
+        RawTable t(8);
+        for (uint64_t i = 0; i < n; ++i) t.put1<uint64_t>(hashes[i]);
+        t.dump(f, kwidth, trailer != 0, slot_seed);
+        return 0;
+    } catch (const std::exception& e) {
+        g_err2 = e.what();
+        return 1;
+    }
+}
+
 int64_t oracle_brute_pairs(const uint64_t* keys, const uint64_t* offsets, uint32_t n_sources, oracle_edge* out,
                            uint64_t capacity) {
     uint64_t ne = 0;

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "kspider_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ksp_[a-z0-9_]+|kspider_pairwise)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(ksp_[a-z0-9_]+|kspider_pairwise[a-z_]*)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -122,3 +122,15 @@ def test_synth_is_deterministic():
     for s in range(a.n_sources):
         r = a.run(s)
         assert (np.diff(r.astype(np.int64) if r.size and r.max() < 2**62 else r.astype(np.float64)) > 0).all()
+
+
+def test_sig_loader_fails_loudly_without_inputs(tmp_path):
+    with pytest.raises(engine.KspError) as ei:
+        engine.pairwise_sigs(str(tmp_path), 31, str(tmp_path / "o"), 1)
+    assert ei.value.code == engine.KSP_E_IO
+    (tmp_path / "bad.sig").write_text('[{"signatures": [{"ksize": 31, "mins": [1, 2, }]}]')
+    with pytest.raises(engine.KspError) as ei:
+        engine.pairwise_sigs(str(tmp_path), 31, str(tmp_path / "o"), 1)
+    assert "malformed JSON" in str(ei.value)
+    with pytest.raises(engine.KspError):
+        engine.pairwise_bins(str(tmp_path), str(tmp_path / "o"), 1)
