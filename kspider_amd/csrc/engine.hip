@@ -296,23 +296,23 @@ __global__ void k_emit_info(const u32* __restrict__ estart, const u32* __restric
     }
 }
 
-// part[b][p] = position (padded layout) of the first key of block b whose rank is
-// >= p * ceil(U / NP)  (p = 0..NP).  Ranks are dense, so equal rank ranges are equal shares
-// of the distinct keys whatever the distribution of the hash values.
-__global__ void k_part(const u32* __restrict__ brk, const u32* __restrict__ blk_raw, const u32* __restrict__ blk_pos,
-                       const u64* __restrict__ scal, u32* __restrict__ part, u32 nb) {
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nb * (NP + 1)) return;
-    u32 b = i / (NP + 1), p = i % (NP + 1);
+// Fine cell index: cidx[b][f] = position (padded layout) of the first key of block b whose rank
+// is >= f * ceil(U / ncell)  (f = 0..ncell).  Ranks are dense, so equal rank ranges are equal
+// shares of the distinct keys whatever the distribution of the hash values.
+__global__ void k_cidx(const u32* __restrict__ brk, const u32* __restrict__ blk_raw, const u32* __restrict__ blk_pos,
+                       const u64* __restrict__ scal, u32* __restrict__ cidx, u32 nb, u32 ncell) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (u64)nb * (ncell + 1)) return;
+    u32 b = (u32)(i / (ncell + 1)), f = (u32)(i % (ncell + 1));
     u32 lo = blk_pos[b], hi = lo + (blk_raw[b + 1] - blk_raw[b]);
-    if (p == NP) { part[i] = hi; return; }
-    u64 step = (scal[2] + NP - 1) / NP;
-    u64 v = (u64)p * step;
+    if (f == ncell) { cidx[i] = hi; return; }
+    u64 step = (scal[2] + ncell - 1) / ncell;
+    u64 v = (u64)f * step;
     while (lo < hi) {
         u32 mid = lo + ((hi - lo) >> 1);
         if ((u64)brk[mid] < v) lo = mid + 1; else hi = mid;
     }
-    part[i] = lo;
+    cidx[i] = lo;
 }
 
 // ------------------------------------------------------------------------------------
@@ -325,7 +325,8 @@ struct JoinArgs {
     const uint4* bigmask; // 128-bit membership masks of the postings with > 4 sources
     const u32* blk_raw; // nb + 1: unpadded distinct-key offsets (counts)
     const u32* blk_pos; // nb + 1: start of every block list in the padded layout
-    const u32* part;    // nb * (NP + 1): positions in the padded layout
+    const u32* cidx;    // nb * (ncell + 1): fine cell index, positions in the padded layout
+    u32 ncell;          // fine cells per block (power of two, >= NP)
     const u32* blk_max; // nb: largest per-source k-mer count (weight sum) in the block
     u32 nb;
     u32 n_sources;
@@ -473,44 +474,282 @@ struct Pending {
 // single source of their block): one LDS atomic per lane, no loop.  Postings with 2..4
 // sources: nested loops with wave-uniform trip counts.  Larger postings: the whole wave
 // expands one match at a time from the 128-bit masks.
+// postings with 2..4 sources, or > 4 (masks): out of line, the hot path stays small
 template <bool C16>
-__device__ inline void pending_apply(u32* S, const uint4* __restrict__ bigmask, const Pending& q, int lane) {
-    const u32 both = q.ia | q.ib;
-    const bool simple = q.valid && both < 128u;
-    if (simple) s_add<C16>(S, (q.ia << 7) | q.ib, q.w);
-    const bool cx = q.valid && !simple;
-    if (__ballot(cx) == 0) return;
+__device__ inline void pending_apply_complex(u32* S, const uint4* __restrict__ bigmask, const u32 qia,
+                                                   const u32 qib, const u32 qw, const bool cx, int lane) {
+    const u32 both = qia | qib;
     const bool small = cx && both < BIG;
-    const u32 nA = small ? (q.ia >> 29) + 1 : 0, nB = small ? (q.ib >> 29) + 1 : 0;
+    const u32 nA = small ? (qia >> 29) + 1 : 0, nB = small ? (qib >> 29) + 1 : 0;
     for (u32 x = 0; x < INLINE_MAX; ++x) {
         if (__ballot(x < nA) == 0) break;
-        const u32 row = ((q.ia >> (7 * x)) & 127u) << 7;
+        const u32 row = ((qia >> (7 * x)) & 127u) << 7;
         for (u32 y = 0; y < INLINE_MAX; ++y) {
             const bool act = x < nA && y < nB;
             if (__ballot(act) == 0) break;
-            if (act) s_add<C16>(S, row | ((q.ib >> (7 * y)) & 127u), q.w);
+            if (act) s_add<C16>(S, row | ((qib >> (7 * y)) & 127u), qw);
         }
     }
     unsigned long long todo = __ballot(cx && !small);
     while (todo) {   // wave-cooperative expansion, one match at a time
         const int src = __builtin_ctzll(todo);
         todo &= todo - 1;
-        const u32 ia = __builtin_amdgcn_readlane(q.ia, src);
-        const u32 ib = __builtin_amdgcn_readlane(q.ib, src);
-        const u32 w = __builtin_amdgcn_readlane(q.w, src);
+        const u32 ia = __builtin_amdgcn_readlane(qia, src);
+        const u32 ib = __builtin_amdgcn_readlane(qib, src);
+        const u32 w = __builtin_amdgcn_readlane(qw, src);
         add_masks<false, C16>(S, posting_mask(ia, bigmask), posting_mask(ib, bigmask), w, lane);
     }
 }
 
+// Apply the pending matches of the wave to the tile.  Fast path (both keys held by a
+// single source of their block): one LDS atomic per lane, no loop.
+template <bool C16>
+__device__ inline void pending_apply(u32* S, const uint4* __restrict__ bigmask, const Pending& q, int lane) {
+    const u32 both = q.ia | q.ib;
+    const bool simple = q.valid && both < 128u;
+    if (simple) s_add<C16>(S, (q.ia << 7) | q.ib, q.w);
+    const bool cx = q.valid && !simple;
+    if (__ballot(cx) != 0) pending_apply_complex<C16>(S, bigmask, q.ia, q.ib, q.w, cx, lane);
+}
+
+// Per-wave LDS state of the join.
+struct WaveLds {
+    Window win;                 // B window as a 4-ary search tree
+    unsigned short mq[WIN];     // match queue: (A slot << 8) | B slot
+};
+
+// One step: every lane looks its 4 A keys (chunk base `ca`) up in the B window (base `cb`);
+// matches are queued, their posting words are fetched (consumed by the NEXT step) and the
+// previous step's matches are applied to the tile.
 template <bool W, bool C16>
+__device__ inline void match_step(const JoinArgs& a, u32* S, WaveLds& wl, const uint4 A0, const uint4 B0,
+                                  const u32 ca, const u32 cb, const bool newB, u32& s0, u32& s1, u32& s2,
+                                  Pending& pend, const int lane) {
+    Window& wn = wl.win;
+    if (newB) {   // (re)build the window of this wave
+        u32* l2w = reinterpret_cast<u32*>(wn.l2);
+        u32* l1w = reinterpret_cast<u32*>(wn.l1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        wn.leaf[lane] = B0;
+        l2w[lane] = B0.w;
+        if ((lane & 3) == 3) l1w[lane >> 2] = B0.w;
+        s0 = __builtin_amdgcn_readlane(B0.w, 15);
+        s1 = __builtin_amdgcn_readlane(B0.w, 31);
+        s2 = __builtin_amdgcn_readlane(B0.w, 47);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    bool h0, h1, h2, h3;
+#ifdef KSP_ABLATE
+    if (a.dbg & 4) { asm volatile("" :: "v"(A0.x), "v"(A0.y), "v"(A0.z), "v"(A0.w)); return; }
+#endif
+    const u32 p0 = window_find(wn, s0, s1, s2, A0.x, h0);
+    const u32 p1 = window_find(wn, s0, s1, s2, A0.y, h1);
+    const u32 p2 = window_find(wn, s0, s1, s2, A0.z, h2);
+    const u32 p3 = window_find(wn, s0, s1, s2, A0.w, h3);
+#ifdef KSP_ABLATE
+    if (a.dbg & 8) { h0 = h1 = h2 = h3 = false; asm volatile("" :: "v"(p0), "v"(p1), "v"(p2), "v"(p3)); }
+#endif
+    // compact the matches (A slot 0..255, B slot 0..255) into the wave's queue
+    unsigned short* q16 = wl.mq;
+    u32 cnt = 0;
+    {
+        const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+        const u32 lo = 4u * lane;
+        if (h0) q16[cnt + __builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, 0))] = (unsigned short)(((lo) << 8) | p0);
+        cnt += (u32)__popcll(m0);
+        if (h1) q16[cnt + __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, 0))] = (unsigned short)(((lo + 1) << 8) | p1);
+        cnt += (u32)__popcll(m1);
+        if (h2) q16[cnt + __builtin_amdgcn_mbcnt_hi((u32)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m2, 0))] = (unsigned short)(((lo + 2) << 8) | p2);
+        cnt += (u32)__popcll(m2);
+        if (h3) q16[cnt + __builtin_amdgcn_mbcnt_hi((u32)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m3, 0))] = (unsigned short)(((lo + 3) << 8) | p3);
+        cnt += (u32)__popcll(m3);
+    }
+    // matches of the previous step: their posting words have arrived by now
+#ifdef KSP_ABLATE
+    if (!(a.dbg & 1))
+#endif
+    pending_apply<C16>(S, a.bigmask, pend, lane);
+    pend.valid = false;
+#ifdef KSP_ABLATE
+    if (a.dbg & 2) cnt = 0;
+#endif
+    // fetch the posting words of this step's matches (consumed by the next step).  Straight-line
+    // for the first 64; the rare surplus (> 64 matches in one step) is gathered and applied at once.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (cnt > 64) {
+        for (u32 base = 64; base < cnt; base += 64) {
+            Pending extra;
+            extra.valid = base + (u32)lane < cnt;
+            extra.ia = 0; extra.ib = 0; extra.w = 1;
+            if (extra.valid) {
+                const u32 e = q16[base + lane];
+                const u32 qa = ca + (e >> 8), qb = cb + (e & 255u);
+                extra.ia = a.info[qa];
+                extra.ib = a.info[qb];
+                if (W) extra.w = a.bw[qa];
+            }
+            pending_apply<C16>(S, a.bigmask, extra, lane);
+        }
+    }
+    {
+        const bool v = (u32)lane < cnt;
+        pend.valid = v;
+        const u32 e = v ? q16[lane] : 0u;
+        const u32 qa = v ? ca + (e >> 8) : ca, qb = v ? cb + (e & 255u) : cb;   // always a valid address
+        pend.ia = a.info[qa];
+        pend.ib = a.info[qb];
+        if (W) pend.w = a.bw[qa];
+    }
+}
+
+// Sliding-window merge of two rank ranges (general: any key distribution).
+template <bool W, bool C16>
+__device__ inline void join_windows(const JoinArgs& a, u32* S, WaveLds& wl, const u32 I, const u32 J, const int wv,
+                                    const int lane) {
+    const u32 stride = a.ncell / NP;   // NP coarse rank ranges out of the fine cell index
+    const u32* cI = a.cidx + (size_t)I * (a.ncell + 1);
+    const u32* cJ = a.cidx + (size_t)J * (a.ncell + 1);
+    for (int p = wv; p < NP; p += JW) {   // equal shares of the key space: static round-robin over waves
+        const u32 pa = __builtin_amdgcn_readfirstlane(cI[p * stride]);
+        const u32 ea = __builtin_amdgcn_readfirstlane(cI[(p + 1) * stride]);
+        const u32 pb = __builtin_amdgcn_readfirstlane(cJ[p * stride]);
+        const u32 eb = __builtin_amdgcn_readfirstlane(cJ[(p + 1) * stride]);
+        if (pa >= ea || pb >= eb) continue;
+        u32 ca = pa & ~3u, cb = pb & ~3u;   // 16-byte aligned bases of the current chunk / window
+        uint4 A0 = load_a(a, ca, pa, ea, lane);
+        uint4 A1 = load_a(a, ca + WIN, pa, ea, lane);
+        uint4 A2 = load_a(a, ca + 2 * WIN, pa, ea, lane);
+        uint4 B0 = load_b(a, cb, eb, lane);
+        uint4 B1 = load_b(a, cb + WIN, eb, lane);
+        uint4 B2 = load_b(a, cb + 2 * WIN, eb, lane);
+        Pending pend;
+        pend.ia = 0; pend.ib = 0; pend.w = 1; pend.valid = false;
+        bool newB = true;
+        u32 s0 = 0, s1 = 0, s2 = 0;
+        while (true) {
+            match_step<W, C16>(a, S, wl, A0, B0, ca, cb, newB, s0, s1, s2, pend, lane);
+            // advance whichever side ends first (both on a tie)
+            const bool afin = ca + WIN >= ea, bfin = cb + WIN >= eb;
+            const u32 aLast = afin ? INF_A : (u32)__builtin_amdgcn_readlane(A0.w, 63);
+            const u32 bLast = bfin ? INF_B : (u32)__builtin_amdgcn_readlane(B0.w, 63);
+            const bool advA = aLast <= bLast, advB = bLast <= aLast;
+            if ((advA && afin) || (advB && bfin)) break;
+            newB = advB;
+            if (advA) {
+                ca += WIN;
+                A0 = A1; A1 = A2;
+                A2 = load_a(a, ca + 2 * WIN, pa, ea, lane);
+            }
+            if (advB) {
+                cb += WIN;
+                B0 = B1; B1 = B2;
+                B2 = load_b(a, cb + 2 * WIN, eb, lane);
+            }
+        }
+        pending_apply<C16>(S, a.bigmask, pend, lane);
+    }
+}
+
+// Rank-aligned cells: both lists are cut at the same rank boundaries (every m-th entry of the
+// fine cell index, m chosen per tile so that a cell holds ~176 keys of the longer list).  A cell
+// is one A chunk against one B window: every A key is searched once, nothing is advanced, and
+// the next two cells are prefetched into two alternating register sets (no register shifting).
+struct CellLoad {
+    uint4 A, B;
+    u32 ca, cb, a0, a1, b0, b1;
+    bool simple, work;
+};
+__device__ inline void cell_fetch(const JoinArgs& a, const u32* cI, const u32* cJ, const u32 c, const u32 cend,
+                                  const u32 m, const int lane, CellLoad& L) {
+    L.simple = false;
+    L.work = false;
+    L.A = make_uint4(INF_A, INF_A, INF_A, INF_A);
+    L.B = make_uint4(PAD, PAD, PAD, PAD);
+    L.ca = L.cb = L.a0 = L.a1 = L.b0 = L.b1 = 0;
+    if (c >= cend) return;   // (only in the last iteration of a wave's range)
+    const u32 f0 = c * m, f1 = min(a.ncell, f0 + m);
+    L.a0 = __builtin_amdgcn_readfirstlane(cI[f0]);
+    L.a1 = __builtin_amdgcn_readfirstlane(cI[f1]);
+    L.b0 = __builtin_amdgcn_readfirstlane(cJ[f0]);
+    L.b1 = __builtin_amdgcn_readfirstlane(cJ[f1]);
+    L.ca = L.a0 & ~3u;
+    L.cb = L.b0 & ~3u;
+    L.work = L.a1 > L.a0 && L.b1 > L.b0;
+    L.simple = L.work && (L.a1 - L.ca <= (u32)WIN) && (L.b1 - L.cb <= (u32)WIN);
+    // always two loads (a fixed instruction stream lets hipcc count its waits); unused ones hit
+    // the cell's own 16-byte aligned start, which is always inside the padded arrays
+    L.A = reinterpret_cast<const uint4*>(a.brk)[(L.ca >> 2) + lane];
+    L.B = reinterpret_cast<const uint4*>(a.brk)[(L.cb >> 2) + lane];
+    if (L.simple && (L.ca < L.a0 || L.ca + WIN > L.a1)) {   // mask A keys outside the cell
+        const u32 p0 = L.ca + 4u * lane;
+        L.A.x = (p0 >= L.a0 && p0 < L.a1) ? L.A.x : INF_A;
+        L.A.y = (p0 + 1 >= L.a0 && p0 + 1 < L.a1) ? L.A.y : INF_A;
+        L.A.z = (p0 + 2 >= L.a0 && p0 + 2 < L.a1) ? L.A.z : INF_A;
+        L.A.w = (p0 + 3 >= L.a0 && p0 + 3 < L.a1) ? L.A.w : INF_A;
+    }
+}
+
+// oversized cell (skewed key distribution): all chunk x window combinations; rare, kept out of line
+template <bool W, bool C16>
+__device__ inline void cell_process_big(const JoinArgs& a, u32* S, WaveLds& wl, const CellLoad& L, u32& s0,
+                                              u32& s1, u32& s2, Pending& pend, const int lane) {
+    for (u32 wb = L.cb; wb < L.b1; wb += WIN) {
+        const uint4 B = load_b(a, wb, L.b1, lane);
+        bool first = true;
+        for (u32 ca = L.ca; ca < L.a1; ca += WIN) {
+            const uint4 A = load_a(a, ca, L.a0, L.a1, lane);
+            match_step<W, C16>(a, S, wl, A, B, ca, wb, first, s0, s1, s2, pend, lane);
+            first = false;
+        }
+    }
+}
+
+template <bool W, bool C16>
+__device__ inline void cell_process(const JoinArgs& a, u32* S, WaveLds& wl, const CellLoad& L, u32& s0, u32& s1,
+                                    u32& s2, Pending& pend, const int lane) {
+    if (L.simple) match_step<W, C16>(a, S, wl, L.A, L.B, L.ca, L.cb, true, s0, s1, s2, pend, lane);
+    else if (L.work) cell_process_big<W, C16>(a, S, wl, L, s0, s1, s2, pend, lane);
+}
+
+template <bool W, bool C16>
+__device__ inline void join_cells(const JoinArgs& a, u32* S, WaveLds& wl, const u32 I, const u32 J, const int wv,
+                                  const int lane) {
+    const u32* cI = a.cidx + (size_t)I * (a.ncell + 1);
+    const u32* cJ = a.cidx + (size_t)J * (a.ncell + 1);
+    const u32 kI = a.blk_raw[I + 1] - a.blk_raw[I], kJ = a.blk_raw[J + 1] - a.blk_raw[J];
+    const u32 kmax = max(max(kI, kJ), 1u);
+    // fine cells per coarse cell: ~176 keys of the longer list (253 fit a window whatever its alignment)
+    u32 m = (u32)(((u64)176 * a.ncell) / kmax);
+    m = __builtin_amdgcn_readfirstlane(max(1u, min(m, a.ncell)));
+    const u32 ncoarse = (a.ncell + m - 1) / m;
+    const u32 cbeg = (u32)(((u64)ncoarse * wv) / JW), cend = (u32)(((u64)ncoarse * (wv + 1)) / JW);
+    // two pending sets, one per unrolled half: a step's posting words are consumed two steps later
+    Pending pend0, pend1;
+    pend0.ia = 0; pend0.ib = 0; pend0.w = 1; pend0.valid = false;
+    pend1 = pend0;
+    u32 s0 = 0, s1 = 0, s2 = 0;
+    CellLoad L0, L1;
+    cell_fetch(a, cI, cJ, cbeg, cend, m, lane, L0);
+    cell_fetch(a, cI, cJ, cbeg + 1, cend, m, lane, L1);
+    for (u32 c = cbeg; c < cend; c += 2) {
+        cell_process<W, C16>(a, S, wl, L0, s0, s1, s2, pend0, lane);
+        cell_fetch(a, cI, cJ, c + 2, cend, m, lane, L0);
+        cell_process<W, C16>(a, S, wl, L1, s0, s1, s2, pend1, lane);
+        cell_fetch(a, cI, cJ, c + 3, cend, m, lane, L1);
+    }
+    pending_apply<C16>(S, a.bigmask, pend0, lane);
+    pending_apply<C16>(S, a.bigmask, pend1, lane);
+}
+
+template <bool W, bool C16, bool CELLS>
 __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
     // pair counters (32 KB packed 16-bit / 64 KB 32-bit) + 8 x (1.3 KB B window + 0.5 KB match
     // queue): three (C16) or two workgroups per CU
     __shared__ u32 S[C16 ? TB * TB / 2 : TB * TB];
-    __shared__ Window win[JW];
-    __shared__ unsigned short mq[JW][WIN];
+    __shared__ WaveLds wlds[JW];
 
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps index arithmetic and loads scalar
     u32 I, J;
     tile_decode(a.tile_begin + blockIdx.x, a.nb, I, J);
     // 16-bit counters are exact iff one of the two blocks has no source with >= 2^16 k-mers
@@ -546,117 +785,10 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
                 add_masks<true, C16>(S, m, m, sw, lane);
             }
         }
+    } else if (CELLS) {
+        join_cells<W, C16>(a, S, wlds[wv], I, J, wv, lane);
     } else {
-        const u32* partI = a.part + (size_t)I * (NP + 1);
-        const u32* partJ = a.part + (size_t)J * (NP + 1);
-        Window& wn = win[wv];
-        u32* l2w = reinterpret_cast<u32*>(wn.l2);
-        u32* l1w = reinterpret_cast<u32*>(wn.l1);
-        // rank-range parts are equal shares of the key space: static round-robin over waves
-        for (int p = wv; p < NP; p += JW) {
-            const u32 pa = __builtin_amdgcn_readfirstlane(partI[p]);
-            const u32 ea = __builtin_amdgcn_readfirstlane(partI[p + 1]);
-            const u32 pb = __builtin_amdgcn_readfirstlane(partJ[p]);
-            const u32 eb = __builtin_amdgcn_readfirstlane(partJ[p + 1]);
-            if (pa >= ea || pb >= eb) continue;
-
-            u32 ca = pa & ~3u, cb = pb & ~3u;   // 16-byte aligned bases of the current chunk / window
-            uint4 A0 = load_a(a, ca, pa, ea, lane);
-            uint4 A1 = load_a(a, ca + WIN, pa, ea, lane);
-            uint4 A2 = load_a(a, ca + 2 * WIN, pa, ea, lane);
-            uint4 B0 = load_b(a, cb, eb, lane);
-            uint4 B1 = load_b(a, cb + WIN, eb, lane);
-            uint4 B2 = load_b(a, cb + 2 * WIN, eb, lane);
-            Pending pend;
-            pend.ia = 0; pend.ib = 0; pend.w = 1; pend.valid = false;
-            unsigned short* q16 = mq[wv];
-            bool newB = true;
-            u32 s0 = 0, s1 = 0, s2 = 0;
-            while (true) {
-                if (newB) {   // (re)build the window of this wave
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    wn.leaf[lane] = B0;
-                    l2w[lane] = B0.w;
-                    if ((lane & 3) == 3) l1w[lane >> 2] = B0.w;
-                    s0 = __builtin_amdgcn_readlane(B0.w, 15);
-                    s1 = __builtin_amdgcn_readlane(B0.w, 31);
-                    s2 = __builtin_amdgcn_readlane(B0.w, 47);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                }
-                // each lane looks its 4 A keys up in the 256-key B window
-                bool h0, h1, h2, h3;
-#ifdef KSP_ABLATE
-                if (a.dbg & 4) { asm volatile("" :: "v"(A0.x), "v"(A0.y), "v"(A0.z), "v"(A0.w)); goto advance; }
-#endif
-                {
-                const u32 p0 = window_find(wn, s0, s1, s2, A0.x, h0);
-                const u32 p1 = window_find(wn, s0, s1, s2, A0.y, h1);
-                const u32 p2 = window_find(wn, s0, s1, s2, A0.z, h2);
-                const u32 p3 = window_find(wn, s0, s1, s2, A0.w, h3);
-#ifdef KSP_ABLATE
-                if (a.dbg & 8) { h0 = h1 = h2 = h3 = false; asm volatile("" :: "v"(p0), "v"(p1), "v"(p2), "v"(p3)); }
-#endif
-                // compact the matches (A slot 0..255, B slot 0..255) into the wave's queue
-                u32 cnt = 0;
-                {
-                    const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
-                    const u32 lo = 4u * lane;
-                    if (h0) q16[cnt + __builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, 0))] = (unsigned short)(((lo) << 8) | p0);
-                    cnt += (u32)__popcll(m0);
-                    if (h1) q16[cnt + __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, 0))] = (unsigned short)(((lo + 1) << 8) | p1);
-                    cnt += (u32)__popcll(m1);
-                    if (h2) q16[cnt + __builtin_amdgcn_mbcnt_hi((u32)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m2, 0))] = (unsigned short)(((lo + 2) << 8) | p2);
-                    cnt += (u32)__popcll(m2);
-                    if (h3) q16[cnt + __builtin_amdgcn_mbcnt_hi((u32)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m3, 0))] = (unsigned short)(((lo + 3) << 8) | p3);
-                    cnt += (u32)__popcll(m3);
-                }
-                // matches of the previous step: their posting words have arrived by now
-#ifdef KSP_ABLATE
-                if (!(a.dbg & 1))
-#endif
-                pending_apply<C16>(S, a.bigmask, pend, lane);
-                pend.valid = false;
-#ifdef KSP_ABLATE
-                if (a.dbg & 2) cnt = 0;
-#endif
-                // fetch the posting words of this step's matches, 64 at a time (consumed next step)
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                for (u32 base = 0; base < cnt; base += 64) {
-                    if (base) pending_apply<C16>(S, a.bigmask, pend, lane);   // rare: > 64 matches in one step
-                    const bool v = base + (u32)lane < cnt;
-                    pend.valid = v;
-                    if (v) {
-                        const u32 e = q16[base + lane];
-                        const u32 qa = ca + (e >> 8), qb = cb + (e & 255u);
-                        pend.ia = a.info[qa];
-                        pend.ib = a.info[qb];
-                        if (W) pend.w = a.bw[qa];
-                    }
-                }
-                }
-#ifdef KSP_ABLATE
-            advance:
-#endif
-                // advance whichever side ends first (both on a tie)
-                const bool afin = ca + WIN >= ea, bfin = cb + WIN >= eb;
-                const u32 aLast = afin ? INF_A : (u32)__builtin_amdgcn_readlane(A0.w, 63);
-                const u32 bLast = bfin ? INF_B : (u32)__builtin_amdgcn_readlane(B0.w, 63);
-                const bool advA = aLast <= bLast, advB = bLast <= aLast;
-                if ((advA && afin) || (advB && bfin)) break;
-                newB = advB;
-                if (advA) {
-                    ca += WIN;
-                    A0 = A1; A1 = A2;
-                    A2 = load_a(a, ca + 2 * WIN, pa, ea, lane);
-                }
-                if (advB) {
-                    cb += WIN;
-                    B0 = B1; B1 = B2;
-                    B2 = load_b(a, cb + 2 * WIN, eb, lane);
-                }
-            }
-            pending_apply<C16>(S, a.bigmask, pend, lane);
-        }
+        join_windows<W, C16>(a, S, wlds[wv], I, J, wv, lane);
     }
     __syncthreads();
 
@@ -711,6 +843,8 @@ struct ksp_engine {
     u64 n_entries = 0;
     bool weighted = false;
     bool built = false;
+    u32 ncell = ksp::NP;          // fine rank cells per block (power of two)
+    bool use_cells = true;        // rank-aligned cell join (KSP_JOIN=window selects the sliding-window merge)
     bool full_sort = false;       // keys defeat the 32-bit prefix sort: use all bits
     bool need32 = false;          // some tile pairs two blocks that both hold a source with >= 2^16 k-mers
     int key_bits = 64;
@@ -746,7 +880,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if ((rc = e->mm.ensure((n / (INLINE_MAX + 1) + 16) * 16))) return rc;   // 128-bit masks of big postings
     if ((rc = e->blk_raw.ensure(((size_t)nb + 2) * 4))) return rc;
     if ((rc = e->blk_pos.ensure(((size_t)nb + 2) * 4))) return rc;
-    if ((rc = e->part.ensure(((size_t)nb + 1) * (NP + 1) * 4))) return rc;
+    if ((rc = e->part.ensure(((size_t)nb + 1) * ((size_t)e->ncell + 1) * 4))) return rc;
     if ((rc = e->blk_max.ensure(((size_t)nb + 2) * 4))) return rc;
     if ((rc = e->scalars.ensure(64))) return rc;
 
@@ -844,8 +978,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     hipLaunchKernelGGL((k_emit_info<V, W>), dim3(grid_for(n, bs)), dim3(bs), 0, st, estart, mmoff, scal, VA,
                        blk_raw, blk_pos, e->info.as<u32>(), e->mm.as<uint4>(), W ? e->bw.as<u32>() : nullptr);
     // rank-range partition of every block list
-    hipLaunchKernelGGL(k_part, dim3(grid_for((u64)nb * (NP + 1), bs)), dim3(bs), 0, st, e->bkeys.as<u32>(),
-                       blk_raw, blk_pos, scal, e->part.as<u32>(), nb);
+    hipLaunchKernelGGL(k_cidx, dim3(grid_for((u64)nb * (e->ncell + 1), bs)), dim3(bs), 0, st, e->bkeys.as<u32>(),
+                       blk_raw, blk_pos, scal, e->part.as<u32>(), nb, e->ncell);
     KSP_HIP(hipGetLastError());
     return KSP_OK;
 }
@@ -931,6 +1065,19 @@ int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_
     if ((rc = e->d_off.ensure(((size_t)n_sources + 1) * 8))) return rc;
     KSP_HIP(hipEventRecord(e->ev[0], st));
     KSP_HIP(hipMemcpyAsync(e->d_off.p, h_offsets, ((size_t)n_sources + 1) * 8, hipMemcpyHostToDevice, st));
+    {   // fine cells: ~32 entries of the largest block per cell, power of two, index kept below 1 GiB
+        u64 dmax = 0;
+        for (u32 b = 0; b < e->nb; ++b) {
+            u64 lo = h_offsets[(u64)b * TB], hi = h_offsets[std::min<u64>(n_sources, (u64)(b + 1) * TB)];
+            dmax = std::max(dmax, hi - lo);
+        }
+        u32 nc = NP;
+        while ((u64)nc * 32 < dmax && nc < (1u << 17)) nc <<= 1;
+        while (nc > NP && (u64)nc * e->nb > (1ull << 28)) nc >>= 1;
+        e->ncell = nc;
+        const char* jm = std::getenv("KSP_JOIN");
+        e->use_cells = !(jm && std::string(jm) == "window");
+    }
     if ((rc = e->blk_max.ensure(((size_t)e->nb + 2) * 4))) return rc;
     e->h_blk_max.assign((size_t)e->nb + 1, 0);
     if (!e->weighted) {   // raw hashes: a source's bound is its k-mer count
@@ -1016,7 +1163,8 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     a.bigmask = e->mm.as<uint4>();
     a.blk_raw = e->blk_raw.as<u32>();
     a.blk_pos = e->blk_pos.as<u32>();
-    a.part = e->part.as<u32>();
+    a.cidx = e->part.as<u32>();
+    a.ncell = e->ncell;
     a.nb = e->nb;
     a.n_sources = e->n_sources;
     a.tile_begin = tile_begin;
@@ -1030,11 +1178,20 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     dim3 grid((unsigned)(tile_end - tile_begin)), block(JW * 64);
     a.blk_max = e->blk_max.as<u32>();
     // packed 16-bit counters wherever they are exact; 32-bit counters for the other tiles
-    if (e->weighted) hipLaunchKernelGGL((k_join<true, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_join<false, true>), grid, block, 0, st, a);
-    if (e->need32) {
-        if (e->weighted) hipLaunchKernelGGL((k_join<true, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_join<false, false>), grid, block, 0, st, a);
+    if (e->use_cells) {
+        if (e->weighted) hipLaunchKernelGGL((k_join<true, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_join<false, true, true>), grid, block, 0, st, a);
+        if (e->need32) {
+            if (e->weighted) hipLaunchKernelGGL((k_join<true, false, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_join<false, false, true>), grid, block, 0, st, a);
+        }
+    } else {
+        if (e->weighted) hipLaunchKernelGGL((k_join<true, true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_join<false, true, false>), grid, block, 0, st, a);
+        if (e->need32) {
+            if (e->weighted) hipLaunchKernelGGL((k_join<true, false, false>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_join<false, false, false>), grid, block, 0, st, a);
+        }
     }
     KSP_HIP(hipGetLastError());
     KSP_HIP(hipEventRecord(e->ev[3], st));
