@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--n-sources", type=int, default=0, help="override the source count (debug)")
-    ap.add_argument("--cpu-sample", type=int, default=4000, help="sources in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=10000, help="sources in the CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -109,11 +109,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    # test hooks (tests/test_bench_gpu.py): several ranks may share one card, exchanging through gloo
+    share_gpu = os.environ.get("KSP_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("KSP_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     base_n = synth.CONFIGS[args.config]["n"]
     n_sources = args.n_sources or int(round(base_n * math.sqrt(world)))
@@ -138,6 +146,8 @@ def main():
         eng.build_blocks(keys_d.data_ptr(), sk.offsets, stream=stream.cuda_stream)
         cnt = eng.join(t0, t1, edges_d.data_ptr(), cap, stream=stream.cuda_stream)
         local = edges_d[:cnt]
+        if world > 1 and backend != "nccl":
+            local = local.cpu()     # gloo exchanges host tensors (test hook only)
         allv = kdist.gather_edges(local, dst=0) if world > 1 else local
         if rank == 0:
             edges_h[: allv.shape[0]].copy_(allv, non_blocking=False)
@@ -147,12 +157,18 @@ def main():
             stats["ms_build"] += st["ms_build"]
             stats["stream_bytes"] = st["last_stream_bytes"]
             stats["edges"] = int(allv.shape[0]) if rank == 0 else cnt
+            if rank == 0 and os.environ.get("KSP_BENCH_CHECKSUM") == "1":
+                ev = edges_h[: allv.shape[0]].numpy().view(engine.EDGE_DTYPE).reshape(-1)
+                stats["checksum"] = int(ev["shared"].sum()) ^ (int(ev["source_1"].astype(np.int64).sum()) << 20) ^ int(
+                    ev["source_2"].astype(np.int64).sum())
         return cnt
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    stats["checksum"] = 0
 
     for _ in range(args.warmup):
         step(False)
@@ -190,6 +206,7 @@ def main():
                                    f"(scaled=1000 hash range), {n} sources, {int(sk.offsets[-1])} hashes; "
                                    f"weak scaling: sources = {base_n}*sqrt(n_gpus)",
                        "n_sources": n, "pairs": total_pairs, "nonzero_pairs": stats["edges"],
+                       "checksum": stats["checksum"],
                        "tiles": T, "parallelism": f"tile-range shard x{world}, stage 1 replicated, "
                                                   f"RCCL p2p gather to rank 0"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

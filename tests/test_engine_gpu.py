@@ -113,3 +113,18 @@ def test_keys_sharing_their_top_bits(oracle_lib):
     giant = base | rng.integers(0, 1 << 31, size=5000, dtype=np.uint64)
     runs = [np.unique(giant[rng.integers(0, giant.size, size=300)]) for _ in range(150)]
     _check(synth.from_runs(runs), oracle_lib)
+
+
+def test_rank_skew_takes_the_oversized_cell_path(oracle_lib):
+    """One block's keys crowd a narrow rank band while the others spread out: cells of that band hold
+    far more than one window of keys (multi-chunk x multi-window fallback of the cell join)."""
+    rng = np.random.default_rng(13)
+    runs = []
+    for s in range(128):                       # block 0: dense band
+        runs.append(np.unique(rng.integers(0, 400_000, size=3000, dtype=np.uint64)))
+    for s in range(260):                       # blocks 1..3: wide spread + a few band keys
+        wide = rng.integers(1 << 20, 1 << 58, size=1500, dtype=np.uint64)
+        band = rng.integers(0, 400_000, size=300, dtype=np.uint64)
+        runs.append(np.unique(np.concatenate([wide, band])))
+    sk = synth.from_runs(runs)
+    _check(sk, oracle_lib)
