@@ -334,6 +334,9 @@ struct JoinArgs {
     ksp_edge* out;
     u64 cap;
     unsigned long long* out_count;
+    u32 n_normal;       // blocks [0, n_normal) own one tile each; the rest split the tail tiles
+    u32 tail_sp;        // workgroups per tail tile (each takes 1/tail_sp of the rank range)
+    u32* tailbuf;       // n_tail x TB*TB 32-bit counters the tail workgroups add into
     u32 dbg;            // timing-only ablation switches (-DKSP_ABLATE builds + KSP_DEBUG_ABLATE; results are wrong when set)
 };
 
@@ -605,11 +608,12 @@ __device__ inline void match_step(const JoinArgs& a, u32* S, WaveLds& wl, const 
 // Sliding-window merge of two rank ranges (general: any key distribution).
 template <bool W, bool C16>
 __device__ inline void join_windows(const JoinArgs& a, u32* S, WaveLds& wl, const u32 I, const u32 J, const int wv,
-                                    const int lane) {
+                                    const int lane, const u32 sub, const u32 sp) {
     const u32 stride = a.ncell / NP;   // NP coarse rank ranges out of the fine cell index
     const u32* cI = a.cidx + (size_t)I * (a.ncell + 1);
     const u32* cJ = a.cidx + (size_t)J * (a.ncell + 1);
-    for (int p = wv; p < NP; p += JW) {   // equal shares of the key space: static round-robin over waves
+    const int pbeg = (int)((NP * sub) / sp), pend_ = (int)((NP * (sub + 1)) / sp);   // this workgroup's share
+    for (int p = pbeg + wv; p < pend_; p += JW) {   // equal shares of the key space: static round-robin over waves
         const u32 pa = __builtin_amdgcn_readfirstlane(cI[p * stride]);
         const u32 ea = __builtin_amdgcn_readfirstlane(cI[(p + 1) * stride]);
         const u32 pb = __builtin_amdgcn_readfirstlane(cJ[p * stride]);
@@ -713,7 +717,7 @@ __device__ inline void cell_process(const JoinArgs& a, u32* S, WaveLds& wl, cons
 
 template <bool W, bool C16>
 __device__ inline void join_cells(const JoinArgs& a, u32* S, WaveLds& wl, const u32 I, const u32 J, const int wv,
-                                  const int lane) {
+                                  const int lane, const u32 sub, const u32 sp) {
     const u32* cI = a.cidx + (size_t)I * (a.ncell + 1);
     const u32* cJ = a.cidx + (size_t)J * (a.ncell + 1);
     const u32 kI = a.blk_raw[I + 1] - a.blk_raw[I], kJ = a.blk_raw[J + 1] - a.blk_raw[J];
@@ -722,7 +726,9 @@ __device__ inline void join_cells(const JoinArgs& a, u32* S, WaveLds& wl, const 
     u32 m = (u32)(((u64)176 * a.ncell) / kmax);
     m = __builtin_amdgcn_readfirstlane(max(1u, min(m, a.ncell)));
     const u32 ncoarse = (a.ncell + m - 1) / m;
-    const u32 cbeg = (u32)(((u64)ncoarse * wv) / JW), cend = (u32)(((u64)ncoarse * (wv + 1)) / JW);
+    // this workgroup's share of the coarse cells (all of them unless it is a tail split), cut into JW wave ranges
+    const u32 wbeg = (u32)(((u64)ncoarse * sub) / sp), wend = (u32)(((u64)ncoarse * (sub + 1)) / sp);
+    const u32 cbeg = wbeg + (u32)(((u64)(wend - wbeg) * wv) / JW), cend = wbeg + (u32)(((u64)(wend - wbeg) * (wv + 1)) / JW);
     // two pending sets, one per unrolled half: a step's posting words are consumed two steps later
     Pending pend0, pend1;
     pend0.ia = 0; pend0.ib = 0; pend0.w = 1; pend0.valid = false;
@@ -741,6 +747,33 @@ __device__ inline void join_cells(const JoinArgs& a, u32* S, WaveLds& wl, const 
     pending_apply<C16>(S, a.bigmask, pend1, lane);
 }
 
+// Compact the non-zero counters of one tile into (source_1, source_2, shared) records:
+// ballot + popcount prefix inside the wave, one global atomic per wave for the output slot.
+template <class Get>
+__device__ inline void emit_tile(const JoinArgs& a, const u32 I, const u32 J, const int tid, const int lane, Get get) {
+    const u32 gi0 = I * TB, gj0 = J * TB;
+    for (int base = 0; base < TB * TB; base += JW * 64) {
+        const int idx = base + tid;
+        const u32 v = get(idx);
+        const bool nz = v != 0;
+        const unsigned long long mask = __ballot(nz);
+        if (mask == 0) continue;
+        unsigned long long wbase = 0;
+        if (lane == 0) wbase = atomicAdd(a.out_count, (unsigned long long)__popcll(mask));
+        wbase = __shfl(wbase, 0);
+        if (nz) {
+            const u64 pos = wbase + __popcll(mask & ((1ull << lane) - 1ull));
+            if (pos < a.cap) {
+                ksp_edge e;
+                e.source_1 = gi0 + (u32)(idx / TB);
+                e.source_2 = gj0 + (u32)(idx % TB);
+                e.shared = v;
+                a.out[pos] = e;
+            }
+        }
+    }
+}
+
 template <bool W, bool C16, bool CELLS>
 __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
     // pair counters (32 KB packed 16-bit / 64 KB 32-bit) + 8 x (1.3 KB B window + 0.5 KB match
@@ -750,10 +783,22 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps index arithmetic and loads scalar
+    // Tail splitting: the tiles of the last, partially filled round of workgroup slots are cut
+    // into tail_sp rank-range shares each, so that the round takes 1/tail_sp of a tile time.
+    u32 sub = 0, sp = 1, tail_id = 0xFFFFFFFFu;
+    u64 tile = a.tile_begin + blockIdx.x;
+    if (blockIdx.x >= a.n_normal) {
+        const u32 r = blockIdx.x - a.n_normal;
+        tail_id = r / a.tail_sp;
+        sub = r % a.tail_sp;
+        sp = a.tail_sp;
+        tile = a.tile_begin + a.n_normal + tail_id;
+    }
     u32 I, J;
-    tile_decode(a.tile_begin + blockIdx.x, a.nb, I, J);
+    tile_decode(tile, a.nb, I, J);
     // 16-bit counters are exact iff one of the two blocks has no source with >= 2^16 k-mers
     if ((min(a.blk_max[I], a.blk_max[J]) < 65536u) != C16) return;
+    if (I == J && sub != 0) return;   // a diagonal tail tile is done by its first share alone
 
     for (int i = tid; i < (C16 ? TB * TB / 2 : TB * TB); i += JW * 64) S[i] = 0;
     __syncthreads();
@@ -786,34 +831,33 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
             }
         }
     } else if (CELLS) {
-        join_cells<W, C16>(a, S, wlds[wv], I, J, wv, lane);
+        join_cells<W, C16>(a, S, wlds[wv], I, J, wv, lane, sub, sp);
     } else {
-        join_windows<W, C16>(a, S, wlds[wv], I, J, wv, lane);
+        join_windows<W, C16>(a, S, wlds[wv], I, J, wv, lane, sub, sp);
     }
     __syncthreads();
 
-    // flush: compact the non-zero counters of the tile into edges
-    const u32 gi0 = I * TB, gj0 = J * TB;
-    for (int base = 0; base < TB * TB; base += JW * 64) {
-        int idx = base + tid;
-        u32 v = C16 ? ((S[idx >> 1] >> ((idx & 1) * 16)) & 0xFFFFu) : S[idx];
-        bool nz = v != 0;
-        unsigned long long mask = __ballot(nz);
-        if (mask == 0) continue;
-        unsigned long long wbase = 0;
-        if (lane == 0) wbase = atomicAdd(a.out_count, (unsigned long long)__popcll(mask));
-        wbase = __shfl(wbase, 0);
-        if (nz) {
-            u64 pos = wbase + __popcll(mask & ((1ull << lane) - 1ull));
-            if (pos < a.cap) {
-                ksp_edge e;
-                e.source_1 = gi0 + (u32)(idx / TB);
-                e.source_2 = gj0 + (u32)(idx % TB);
-                e.shared = v;
-                a.out[pos] = e;
-            }
+    if (tail_id != 0xFFFFFFFFu) {
+        // tail share: add the partial counters into the tile's global buffer (k_tail_emit compacts it)
+        u32* dst = a.tailbuf + (size_t)tail_id * (TB * TB);
+        for (int base = 0; base < TB * TB; base += JW * 64) {
+            const int idx = base + tid;
+            const u32 v = C16 ? ((S[idx >> 1] >> ((idx & 1) * 16)) & 0xFFFFu) : S[idx];
+            if (v) atomicAdd(&dst[idx], v);
         }
+        return;
     }
+    // flush: compact the non-zero counters of the tile into edges
+    emit_tile(a, I, J, tid, lane, [&](int idx) { return C16 ? ((S[idx >> 1] >> ((idx & 1) * 16)) & 0xFFFFu) : S[idx]; });
+}
+
+// one workgroup per tail tile: its summed counters -> edges
+__global__ __launch_bounds__(JW * 64) void k_tail_emit(JoinArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    u32 I, J;
+    tile_decode(a.tile_begin + a.n_normal + blockIdx.x, a.nb, I, J);
+    const u32* src = a.tailbuf + (size_t)blockIdx.x * (TB * TB);
+    emit_tile(a, I, J, tid, lane, [&](int idx) { return src[idx]; });
 }
 
 // ------------------------------------------------------------------------------------
@@ -852,7 +896,8 @@ struct ksp_engine {
     std::vector<u32> h_blk_off;   // distinct-key offsets of the block lists (host copy)
     std::vector<u32> h_blk_max;   // per block: largest per-source k-mer count / weight sum
     // workspace
-    ksp::Buf d_off, KA, KB, VA, VB, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, blk_max, part, scalars, count;
+    ksp::Buf d_off, KA, KB, VA, VB, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, blk_max, part, scalars, count, tailbuf;
+    u32 slots = 0;                // workgroups of k_join the chip holds at once (occupancy x CUs)
     unsigned long long* h_count = nullptr;   // pinned
     u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1023,7 +1068,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->tmp, &e->bkeys, &e->info,
-                        &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count};
+                        &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
@@ -1175,22 +1220,57 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     if (const char* dbg = std::getenv("KSP_DEBUG_ABLATE")) a.dbg = (u32)std::atoi(dbg);
     KSP_HIP(hipMemsetAsync(a.out_count, 0, 8, st));
     KSP_HIP(hipEventRecord(e->ev[2], st));
-    dim3 grid((unsigned)(tile_end - tile_begin)), block(JW * 64);
+    dim3 block(JW * 64);
     a.blk_max = e->blk_max.as<u32>();
+    const u32 ntiles = (u32)(tile_end - tile_begin);
+    // Tile splitting for small launches: when there are fewer tiles than workgroup slots on the chip,
+    // every tile is cut into `sp` rank-range shares (partial counters are summed in a global buffer).
+    u32 n_tail = 0, sp = 1;
+    if (e->slots == 0) {
+        int per_cu = 0, cus = 0;
+        KSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_join<false, true, true>, JW * 64, 0));
+        KSP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+        e->slots = (u32)std::max(1, per_cu * cus);
+    }
+    // (Measured on C2, 3160 tiles on 768 slots: splitting the 88 "remainder" tiles does not pay — tiles
+    //  finish at different times and the dispatcher back-fills — so only under-filled launches split.)
+    if (!std::getenv("KSP_NO_TAIL_SPLIT")) {
+        const u32 r = ntiles < e->slots ? ntiles : 0;
+        if (r > 0 && (u64)r * 4 <= (u64)e->slots * 3) {
+            sp = std::min<u32>(8, e->slots / r);
+            if (sp >= 2) n_tail = r; else sp = 1;
+        }
+    }
+    a.n_normal = ntiles - n_tail;
+    a.tail_sp = sp;
+    a.tailbuf = nullptr;
+    if (n_tail) {
+        if ((rc = e->tailbuf.ensure((size_t)n_tail * TB * TB * 4))) return rc;
+        a.tailbuf = e->tailbuf.as<u32>();
+        KSP_HIP(hipMemsetAsync(a.tailbuf, 0, (size_t)n_tail * TB * TB * 4, st));
+    }
+    dim3 grid(a.n_normal + n_tail * sp);
     // packed 16-bit counters wherever they are exact; 32-bit counters for the other tiles
     if (e->use_cells) {
         if (e->weighted) hipLaunchKernelGGL((k_join<true, true, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((k_join<false, true, true>), grid, block, 0, st, a);
-        if (e->need32) {
-            if (e->weighted) hipLaunchKernelGGL((k_join<true, false, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_join<false, false, true>), grid, block, 0, st, a);
-        }
     } else {
         if (e->weighted) hipLaunchKernelGGL((k_join<true, true, false>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((k_join<false, true, false>), grid, block, 0, st, a);
-        if (e->need32) {
-            if (e->weighted) hipLaunchKernelGGL((k_join<true, false, false>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_join<false, false, false>), grid, block, 0, st, a);
+    }
+    if (n_tail) hipLaunchKernelGGL(k_tail_emit, dim3(n_tail), block, 0, st, a);
+    if (e->need32) {   // tiles whose two blocks both hold huge sketches: one workgroup per tile, no tail split
+        JoinArgs b = a;
+        b.n_normal = ntiles;
+        b.tail_sp = 1;
+        b.tailbuf = nullptr;
+        dim3 grid32(ntiles);
+        if (e->use_cells) {
+            if (e->weighted) hipLaunchKernelGGL((k_join<true, false, true>), grid32, block, 0, st, b);
+            else hipLaunchKernelGGL((k_join<false, false, true>), grid32, block, 0, st, b);
+        } else {
+            if (e->weighted) hipLaunchKernelGGL((k_join<true, false, false>), grid32, block, 0, st, b);
+            else hipLaunchKernelGGL((k_join<false, false, false>), grid32, block, 0, st, b);
         }
     }
     KSP_HIP(hipGetLastError());
