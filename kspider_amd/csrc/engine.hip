@@ -62,6 +62,7 @@ void set_error(const std::string& s) { g_error = s; }
 constexpr int TB = 128;       // sources per block (tile edge)
 constexpr int NP = 64;        // value-range parts per block (intra-tile work items)
 constexpr int JW = 8;         // waves per join workgroup
+constexpr int CELL_TARGET = 216;  // mean keys of the longer list per cell (253 always fit a window)
 constexpr int WIN = 256;      // keys per chunk / LDS window: 4 per lane of a wavefront
 constexpr u32 BIG = 0xE0000000u;      // posting word: more than INLINE_MAX sources, mask index in the low bits
 constexpr u32 INLINE_MAX = 4;         // sources whose 7-bit ids fit into the posting word
@@ -723,7 +724,7 @@ __device__ inline void join_cells(const JoinArgs& a, u32* S, WaveLds& wl, const 
     const u32 kI = a.blk_raw[I + 1] - a.blk_raw[I], kJ = a.blk_raw[J + 1] - a.blk_raw[J];
     const u32 kmax = max(max(kI, kJ), 1u);
     // fine cells per coarse cell: ~176 keys of the longer list (253 fit a window whatever its alignment)
-    u32 m = (u32)(((u64)176 * a.ncell) / kmax);
+    u32 m = (u32)(((u64)CELL_TARGET * a.ncell) / kmax);
     m = __builtin_amdgcn_readfirstlane(max(1u, min(m, a.ncell)));
     const u32 ncoarse = (a.ncell + m - 1) / m;
     // this workgroup's share of the coarse cells (all of them unless it is a tail split), cut into JW wave ranges
