@@ -37,6 +37,8 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_reduce.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "../../include/kspider_amd.h"
 #include "engine_internal.h"
@@ -178,13 +180,37 @@ __global__ void k_fix_runs(u64* __restrict__ keys, V* __restrict__ vals, u64 n, 
     }
 }
 
-// After the global sort by key: flag[e] = 1 where a new distinct key starts (0 at e = 0),
-// so that inclusive_scan(flag) is the key's dense rank — an exact, order-preserving
-// 32-bit stand-in for the 64-bit hash.
-__global__ void k_flag_keys(const u64* __restrict__ keys, u32* __restrict__ flag, u64 n) {
+// Singleton pruning + dense ranks, after the global sort by key.  A key held by exactly one
+// source (a run of length 1) cannot contribute to any pair: its entry is dropped, which
+// shortens every block list (less to stream and search in the join) and all later passes.
+// The kept keys get dense ranks 0..U-1 — an exact, order-preserving 32-bit stand-in for the
+// 64-bit hash.  One scan over packed counters: low word = kept entries, high word = kept keys.
+struct PruneFn {
+    const u64* keys;
+    u64 n;
+    __device__ u64 operator()(u64 e) const {
+        const u64 k = keys[e];
+        const bool head = e == 0 || keys[e - 1] != k;
+        const bool last = e + 1 == n || keys[e + 1] != k;
+        const bool single = head && last;
+        return (single ? 0ull : 1ull) | ((u64)(head && !single) << 32);
+    }
+};
+template <class V>
+__global__ void k_prune_scatter(const V* __restrict__ vals, const u64* __restrict__ ps, V* __restrict__ vals2,
+                                u32* __restrict__ rank2, u64* __restrict__ scal, u64 n) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    flag[e] = (e > 0 && keys[e] != keys[e - 1]) ? 1u : 0u;
+    const u64 cur = ps[e];
+    const u32 lo = (u32)cur, prev = e ? (u32)ps[e - 1] : 0u;
+    if (lo != prev) {   // kept entry
+        vals2[lo - 1] = vals[e];
+        rank2[lo - 1] = (u32)(cur >> 32) - 1u;
+    }
+    if (e == n - 1) {
+        scal[6] = lo;                 // kept entries
+        scal[2] = (u32)(cur >> 32);   // kept distinct keys (U)
+    }
 }
 
 // flag[e] = 1 when entry e opens a new (block, rank) group.
@@ -207,18 +233,19 @@ __global__ void k_ktot(const u32* __restrict__ flag, const u32* __restrict__ did
     }
 }
 
-__global__ void k_store_u(const u32* __restrict__ rank_by_key, u64* __restrict__ scal, u64 n) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) scal[2] = (u64)rank_by_key[n - 1] + 1;
-}
-
-// raw (unpadded) first distinct-key index of each block: entries of a block are contiguous.
-__global__ void k_blk_raw(const u64* __restrict__ off, const u32* __restrict__ didx, const u64* __restrict__ scal,
-                          u32* __restrict__ blk_raw, u32 nb, u32 n_sources, u64 n) {
+// raw (unpadded) first distinct-key index of each block: entries are sorted by block, so the
+// first entry of block b is found by bisection over the tags.
+template <class V>
+__global__ void k_blk_raw(const V* __restrict__ vals, const u32* __restrict__ didx, const u64* __restrict__ scal,
+                          u32* __restrict__ blk_raw, u32 nb, u64 n) {
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nb) return;
-    u64 s = (u64)b * TB;
-    u64 es = off[s < n_sources ? s : n_sources];
-    blk_raw[b] = (es < n) ? didx[es] : (u32)scal[1];
+    u64 lo = 0, hi = n;
+    while (lo < hi) {
+        u64 mid = lo + ((hi - lo) >> 1);
+        if ((tag_of(vals[mid]) >> 8) < b) lo = mid + 1; else hi = mid;
+    }
+    blk_raw[b] = (lo < n) ? didx[lo] : (u32)scal[1];
 }
 
 // Padded layout of the block lists: every list starts at a multiple of 4 entries and is
@@ -886,6 +913,7 @@ struct ksp_engine {
     // inputs / geometry
     u32 n_sources = 0, nb = 0;
     u64 n_entries = 0;
+    u64 n_kept = 0;               // entries whose key is held by >= 2 sources (the others are pruned)
     bool weighted = false;
     bool built = false;
     u32 ncell = ksp::NP;          // fine rank cells per block (power of two)
@@ -897,7 +925,7 @@ struct ksp_engine {
     std::vector<u32> h_blk_off;   // distinct-key offsets of the block lists (host copy)
     std::vector<u32> h_blk_max;   // per block: largest per-source k-mer count / weight sum
     // workspace
-    ksp::Buf d_off, KA, KB, VA, VB, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, blk_max, part, scalars, count, tailbuf;
+    ksp::Buf d_off, KA, KB, VA, VB, R1, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, blk_max, part, scalars, count, tailbuf;
     u32 slots = 0;                // workgroups of k_join the chip holds at once (occupancy x CUs)
     unsigned long long* h_count = nullptr;   // pinned
     u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
@@ -983,45 +1011,53 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         hipLaunchKernelGGL((k_fix_runs<V>), dim3(4096), dim3(64), 0, st, KA, VB, n, shift, fixlist, d_cnt, fixcap,
                            d_ovf);
     }
-    // dense rank of every key: exact 32-bit stand-in for the hash
-    u32* kflag = (u32*)e->KB.p;            // n
-    u32* krank = (u32*)e->KB.p + (n + 2);  // n
-    hipLaunchKernelGGL(k_flag_keys, dim3(grid_for(n, bs)), dim3(bs), 0, st, KA, kflag, n);
-    tb = 0;
-    KSP_HIP(rocprim::inclusive_scan(nullptr, tb, kflag, krank, n, rocprim::plus<u32>(), st));
-    if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::inclusive_scan(e->tmp.p, tb, kflag, krank, n, rocprim::plus<u32>(), st));
-    hipLaunchKernelGGL(k_store_u, dim3(1), dim3(64), 0, st, krank, scal, n);
-    // sort 2: stable by block id (bits [8, 8+bbits) of the tag), payload = rank:  VB,krank -> VA,rk2
+    // singleton pruning + dense ranks of the kept keys (packed counters, one scan):  KA,VB -> R1 (ranks), VA (tags)
+    if ((rc = e->R1.ensure((n + 4) * 4))) return rc;
+    u64* ps = (u64*)e->KB.p;               // n packed prefix sums
+    u32* rank1 = e->R1.as<u32>();
+    {
+        auto pf = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u64>(0), PruneFn{KA, n});
+        tb = 0;
+        KSP_HIP(rocprim::inclusive_scan(nullptr, tb, pf, ps, n, rocprim::plus<u64>(), st));
+        if ((rc = e->tmp.ensure(tb))) return rc;
+        KSP_HIP(rocprim::inclusive_scan(e->tmp.p, tb, pf, ps, n, rocprim::plus<u64>(), st));
+    }
+    hipLaunchKernelGGL((k_prune_scatter<V>), dim3(grid_for(n, bs)), dim3(bs), 0, st, VB, ps, VA, rank1, scal, n);
+    KSP_HIP(hipMemcpyAsync(e->h_scal + 6, scal + 6, 8, hipMemcpyDeviceToHost, st));
+    KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
+    const u64 m = e->h_scal[6];
+    e->n_kept = m;
+    if (m == 0) return KSP_OK;             // no key is shared by two sources: no pair at all
+    // sort 2: stable by block id (bits [8, 8+bbits) of the tag), payload = rank:  VA,rank1 -> VB,rk2
     u32* rk2 = (u32*)KA;                   // KA (sorted keys) is dead from here on
     tb = 0;
-    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, VB, VA, krank, rk2, n, 8, 8 + bbits, st));
+    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, VA, VB, rank1, rk2, m, 8, 8 + bbits, st));
     if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, VB, VA, krank, rk2, n, 8, 8 + bbits, st));
-    // now: rk2 = ranks sorted by (block, rank); VA = tags in the same order.  KB, VB are free.
-    u32* flag = (u32*)VB;
-    u32* didx = (u32*)e->KB.p;             // n
-    u32* estart = (u32*)e->KB.p + (n + 2); // up to n+1
-    hipLaunchKernelGGL((k_heads<V>), dim3(grid_for(n, bs)), dim3(bs), 0, st, rk2, VA, flag, n);
+    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, VA, VB, rank1, rk2, m, 8, 8 + bbits, st));
+    // now: rk2 = ranks sorted by (block, rank); VB = tags in the same order.  KB, VA, R1 are free.
+    V* T = VB;
+    u32* flag = (u32*)VA;
+    u32* didx = (u32*)e->KB.p;             // m
+    u32* estart = (u32*)e->KB.p + (n + 2); // up to m+1
+    hipLaunchKernelGGL((k_heads<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rk2, T, flag, m);
     tb = 0;
-    KSP_HIP(rocprim::exclusive_scan(nullptr, tb, flag, didx, (u32)0, n, rocprim::plus<u32>(), st));
+    KSP_HIP(rocprim::exclusive_scan(nullptr, tb, flag, didx, (u32)0, m, rocprim::plus<u32>(), st));
     if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, flag, didx, (u32)0, n, rocprim::plus<u32>(), st));
-    hipLaunchKernelGGL(k_ktot, dim3(1), dim3(64), 0, st, flag, didx, estart, scal, n);
-    hipLaunchKernelGGL(k_blk_raw, dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, d_off, didx, scal, blk_raw, nb,
-                       N, n);
+    KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, flag, didx, (u32)0, m, rocprim::plus<u32>(), st));
+    hipLaunchKernelGGL(k_ktot, dim3(1), dim3(64), 0, st, flag, didx, estart, scal, m);
+    hipLaunchKernelGGL((k_blk_raw<V>), dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, T, didx, scal, blk_raw, nb, m);
     hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, blk_raw, blk_pos, scal, nb);
     hipLaunchKernelGGL(k_fill, dim3(grid_for(lmax, bs)), dim3(bs), 0, st, e->bkeys.as<u32>(), PAD, lmax);
-    hipLaunchKernelGGL((k_emit_keys<V>), dim3(grid_for(n, bs)), dim3(bs), 0, st, rk2, VA, flag, didx, blk_raw,
-                       blk_pos, e->bkeys.as<u32>(), estart, n);
+    hipLaunchKernelGGL((k_emit_keys<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rk2, T, flag, didx, blk_raw,
+                       blk_pos, e->bkeys.as<u32>(), estart, m);
     u32* mmsz = flag;                      // flags are dead now
     u32* mmoff = (u32*)KA;                 // rk2 is dead after k_emit_keys
-    hipLaunchKernelGGL(k_bigflag, dim3(grid_for(n, bs)), dim3(bs), 0, st, estart, scal, mmsz, n);
+    hipLaunchKernelGGL(k_bigflag, dim3(grid_for(m, bs)), dim3(bs), 0, st, estart, scal, mmsz, m);
     tb = 0;
-    KSP_HIP(rocprim::exclusive_scan(nullptr, tb, mmsz, mmoff, (u32)0, n, rocprim::plus<u32>(), st));
+    KSP_HIP(rocprim::exclusive_scan(nullptr, tb, mmsz, mmoff, (u32)0, m, rocprim::plus<u32>(), st));
     if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, mmsz, mmoff, (u32)0, n, rocprim::plus<u32>(), st));
-    hipLaunchKernelGGL((k_emit_info<V, W>), dim3(grid_for(n, bs)), dim3(bs), 0, st, estart, mmoff, scal, VA,
+    KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, mmsz, mmoff, (u32)0, m, rocprim::plus<u32>(), st));
+    hipLaunchKernelGGL((k_emit_info<V, W>), dim3(grid_for(m, bs)), dim3(bs), 0, st, estart, mmoff, scal, T,
                        blk_raw, blk_pos, e->info.as<u32>(), e->mm.as<uint4>(), W ? e->bw.as<u32>() : nullptr);
     // rank-range partition of every block list
     hipLaunchKernelGGL(k_cidx, dim3(grid_for((u64)nb * (e->ncell + 1), bs)), dim3(bs), 0, st, e->bkeys.as<u32>(),
@@ -1068,7 +1104,7 @@ int ksp_engine_create(int device, ksp_engine** out) {
 void ksp_engine_destroy(ksp_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->tmp, &e->bkeys, &e->info,
+    ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
@@ -1102,6 +1138,7 @@ int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_
     e->st.n_blocks = e->nb;
     e->st.n_tiles = (u64)e->nb * (e->nb + 1) / 2;
     e->st.weighted = e->weighted;
+    e->n_kept = 0;
     if (n == 0 || e->nb == 0) {   // nothing can intersect
         e->built = true;
         e->st.key_bits = 0;
@@ -1146,6 +1183,14 @@ int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_
         e->full_sort = true;
     }
     KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
+    e->st.key_bits = e->key_bits;
+    if (e->n_kept == 0) {   // no key is held by two sources: every pair count is zero
+        e->st.n_block_keys = 0;
+        e->h_blk_off.assign((size_t)e->nb + 1, 0);
+        e->need32 = false;
+        e->built = true;
+        return KSP_OK;
+    }
     e->st.n_block_keys = e->h_scal[1];
     if (e->weighted)
         KSP_HIP(hipMemcpy(e->h_blk_max.data(), e->blk_max.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
@@ -1197,7 +1242,7 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     if (tile_end > T) tile_end = T;
     *h_count = 0;
     e->st.last_tiles = 0; e->st.last_pairs = 0; e->st.last_edges = 0; e->st.last_stream_bytes = 0; e->st.ms_join = 0;
-    if (tile_begin >= tile_end || e->n_entries == 0) return KSP_OK;
+    if (tile_begin >= tile_end || e->n_entries == 0 || e->n_kept == 0) return KSP_OK;
     if (capacity && !d_edges) { set_error("join: d_edges is NULL"); return KSP_E_ARG; }
     if (tile_end - tile_begin > 0x7FFFFFFFull) { set_error("join: more than 2^31 tiles in one launch"); return KSP_E_LIMIT; }
     int rc;
