@@ -6,7 +6,8 @@
 
 One "step" = one pass of the hot path over one batch of synthetic sketches that already
 sit in HBM as sorted uint64 runs:
-    stage 1  build_blocks  (rank-encode + merge the runs of every 128-source block)
+    stage 1  build_blocks  (prune singletons, rank-encode, merge the runs of every 128-source block;
+                            N > 1: per-rank hash-range slices + all-gather + assemble)
     stage 2  join          (LDS-tiled intersection of this rank's tile range -> edges in HBM)
     gather   RCCL point-to-point gather of the edge lists to rank 0 (N > 1 only)
     D2H      rank 0 copies the edges to pinned host memory (the hand-over to the TSV writer)
@@ -14,8 +15,9 @@ sit in HBM as sorted uint64 runs:
 Workload: BASELINE.json configs[1] ("10k sourmash signatures, scaled=1000, k=31" ->
 synthetic C2: 10 000 sketches, n ~ N(5000, 1500), hashes < 2^64/1000).  N > 1 is WEAK
 scaling: the source count grows as 10 000 * sqrt(N) so that every GPU keeps the pair count
-of the 1-GPU job; stage 1 is replicated on every rank (no data-path collective), tiles are
-sharded, and the final gather is the only exchange step.
+of the 1-GPU job; every rank holds the full sketch set; stage 1 is sharded by hash range
+(rank r builds the block-list slices of its 1/N share of the keys; the slices are exchanged
+with one RCCL all-gather), tiles are sharded, and the edges are gathered to rank 0.
 
 value = whole-job source pairs per second = [S(S-1)/2] * K / t, t = max over ranks of the
 wall time of K steps bracketed by barrier + torch.cuda.synchronize().
@@ -140,10 +142,16 @@ def main():
     host_cap = int(min(total_pairs, 1 << 27)) + 1
     edges_h = torch.empty((host_cap, 16), dtype=torch.uint8).pin_memory() if rank == 0 else None
 
-    stats = {"ms_join": 0.0, "ms_build": 0.0, "edges": 0, "stream_bytes": 0}
+    stats = {"ms_join": 0.0, "ms_build": 0.0, "edges": 0, "stream_bytes": 0, "xchg_bytes": 0}
+
+    sharded = world > 1 and os.environ.get("KSP_BENCH_REPLICATED_BUILD") != "1"
 
     def step(record: bool):
-        eng.build_blocks(keys_d.data_ptr(), sk.offsets, stream=stream.cuda_stream)
+        if sharded:   # stage 1 sharded by hash range + all-gather of the block-list slices
+            stats["xchg_bytes"] = kdist.build_blocks_sharded(eng, keys_d.data_ptr(), sk.offsets, world, rank, dev,
+                                                             stream=stream.cuda_stream)
+        else:
+            eng.build_blocks(keys_d.data_ptr(), sk.offsets, stream=stream.cuda_stream)
         cnt = eng.join(t0, t1, edges_d.data_ptr(), cap, stream=stream.cuda_stream)
         local = edges_d[:cnt]
         if world > 1 and backend != "nccl":
@@ -207,8 +215,11 @@ def main():
                                    f"weak scaling: sources = {base_n}*sqrt(n_gpus)",
                        "n_sources": n, "pairs": total_pairs, "nonzero_pairs": stats["edges"],
                        "checksum": stats["checksum"],
-                       "tiles": T, "parallelism": f"tile-range shard x{world}, stage 1 replicated, "
-                                                  f"RCCL p2p gather to rank 0"},
+                       "tiles": T,
+                       "parallelism": (f"tile-range shard x{world}; stage 1 "
+                                       + ("sharded by hash range + RCCL all-gather of the block-list slices "
+                                          f"({stats['xchg_bytes'] / 1e6:.0f} MB received per rank)" if sharded
+                                          else "replicated") + "; RCCL p2p gather of the edges to rank 0")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "ksp::k_join", "ms_per_launch": ms_join,

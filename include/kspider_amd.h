@@ -85,6 +85,29 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
 
 int ksp_engine_get_stats(const ksp_engine* e, ksp_stats* out);
 
+/* ---- stage 1 sharded over GPUs (one process per GPU) ---------------------------------------
+ * Every rank holds the full sketch set; rank `part` of `nparts` builds the block lists of the
+ * keys in its 1/nparts share of the hash range only (ksp_engine_build_slice), the slices are
+ * exchanged by the caller (all-gather over RCCL: kspider_amd/dist.py), and every rank turns the
+ * gathered slices into the full block lists (ksp_engine_assemble) before ksp_engine_join.
+ *   slice_sizes: out[0] padded list length L (uint32 entries of d_brk / d_info / d_bw),
+ *                out[1] distinct keys, out[2] 128-bit posting masks, out[3] block keys.
+ *   slice_export: copies the slice into caller buffers (device pointers): d_brk/d_info[/d_bw] L
+ *                entries, d_blk_raw/d_blk_pos n_blocks+1 entries, d_big out[2] x 16 bytes.
+ *   assemble:    h_sizes = nparts x 4 values as reported by slice_sizes (host); the *_all buffers
+ *                hold the parts back to back with strides lstride (entries) / n_blocks+1 /
+ *                bigstride (16-byte masks); must run on an engine that built one of the slices. */
+int ksp_engine_build_slice(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights,
+                           const uint64_t* h_offsets, uint32_t n_sources, int key_bits, uint32_t part,
+                           uint32_t nparts, void* stream);
+int ksp_engine_slice_sizes(const ksp_engine* e, uint64_t out[4]);
+int ksp_engine_slice_export(ksp_engine* e, uint32_t* d_brk, uint32_t* d_info, uint32_t* d_bw, uint32_t* d_blk_raw,
+                            uint32_t* d_blk_pos, void* d_big, void* stream);
+int ksp_engine_assemble(ksp_engine* e, uint32_t nparts, const uint64_t* h_sizes, const uint32_t* d_brk_all,
+                        const uint32_t* d_info_all, const uint32_t* d_bw_all, uint64_t lstride,
+                        const uint32_t* d_blk_raw_all, const uint32_t* d_blk_pos_all, const void* d_big_all,
+                        uint64_t bigstride, void* stream);
+
 /* ---- thin device-memory helpers so that FFI callers need no HIP binding ------------- */
 int ksp_device_malloc(int device, uint64_t bytes, void** d_ptr);
 int ksp_device_free(void* d_ptr);

@@ -343,6 +343,94 @@ __global__ void k_cidx(const u32* __restrict__ brk, const u32* __restrict__ blk_
     cidx[i] = lo;
 }
 
+// ---- key-range slices (multi-GPU build) -----------------------------------------------
+// Rank p of G builds the block lists of the keys in its 1/G share of the hash range only
+// (filter -> same pipeline on n/G entries); the slices are exchanged (all-gather) and every
+// rank assembles the full lists: slice p's ranks are shifted by the number of distinct keys
+// of the slices before it, so concatenating the slices of a block in part order is sorted.
+// Every source's run is sorted, so its keys inside [lo, hi] are one contiguous sub-run: two
+// bisections per source instead of a pass over all entries.
+__global__ void k_range_bounds(const u64* __restrict__ keys, const u64* __restrict__ off, u64 lo, u64 hi,
+                               u32* __restrict__ first, u32* __restrict__ cnt, u32 n_sources) {
+    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sources) return;
+    const u64 b = off[s], e = off[s + 1];
+    u64 l = b, r = e;
+    while (l < r) { u64 m = l + ((r - l) >> 1); if (keys[m] < lo) l = m + 1; else r = m; }
+    const u64 a = l;
+    r = e;
+    while (l < r) { u64 m = l + ((r - l) >> 1); if (keys[m] <= hi) l = m + 1; else r = m; }
+    first[s] = (u32)(a - b);
+    cnt[s] = (u32)(l - a);
+}
+// one workgroup per source: copy its sub-run and tag it (block << 8 | local id [| weight << 32])
+template <class V, bool W>
+__global__ void k_range_copy(const u64* __restrict__ keys, const u32* __restrict__ wts, const u64* __restrict__ off,
+                             const u32* __restrict__ first, const u32* __restrict__ cnt, const u32* __restrict__ fpos,
+                             u64* __restrict__ fkeys, V* __restrict__ ftags) {
+    const u32 s = blockIdx.x;
+    const u64 src = off[s] + first[s];
+    const u32 c = cnt[s], dst = fpos[s];
+    const u32 tag = ((s / TB) << 8) | (s % TB);
+    for (u32 i = threadIdx.x; i < c; i += blockDim.x) {
+        fkeys[dst + i] = keys[src + i];
+        if (W) ftags[dst + i] = (V)(((u64)wts[src + i] << 32) | tag);
+        else ftags[dst + i] = (V)tag;
+    }
+}
+__global__ void k_range_total(const u32* __restrict__ fpos, const u32* __restrict__ cnt, u64* __restrict__ scal, u32 n_sources) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[8] = (u64)fpos[n_sources - 1] + cnt[n_sources - 1];
+}
+// largest key = largest last element of the sorted runs
+__global__ void k_max_last(const u64* __restrict__ keys, const u64* __restrict__ off, unsigned long long* __restrict__ out,
+                           u32 n_sources) {
+    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (s < n_sources && off[s + 1] > off[s]) v = keys[off[s + 1] - 1];
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned long long)__shfl_down(v, o));
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
+}
+
+__global__ void k_nbig(const u32* __restrict__ bigflag, const u32* __restrict__ bigoff, u64* __restrict__ scal) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const u64 k = scal[1];
+        scal[7] = k ? (u64)bigoff[k - 1] + bigflag[k - 1] : 0;
+    }
+}
+// global block counts from the parts' counts (serial: nb x parts is small)
+__global__ void k_asm_counts(const u32* __restrict__ raw_all, u32 stride, u32 nparts, u32 nb, u32* __restrict__ blk_raw) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        u32 acc = 0;
+        for (u32 b = 0; b < nb; ++b) {
+            blk_raw[b] = acc;
+            for (u32 p = 0; p < nparts; ++p) acc += raw_all[(size_t)p * stride + b + 1] - raw_all[(size_t)p * stride + b];
+        }
+        blk_raw[nb] = acc;
+    }
+}
+// one workgroup per (block, part): copy the part's slice of the block into the full list
+template <bool W>
+__global__ void k_asm_copy(const u32* __restrict__ brk_all, const u32* __restrict__ info_all,
+                           const u32* __restrict__ bw_all, size_t lstride, const u32* __restrict__ raw_all,
+                           const u32* __restrict__ pos_all, u32 bstride, const u32* __restrict__ rank_off,
+                           const u32* __restrict__ big_off, const u32* __restrict__ blk_pos, u32* __restrict__ brk,
+                           u32* __restrict__ info, u32* __restrict__ bw) {
+    const u32 b = blockIdx.x, p = blockIdx.y;
+    u32 before = 0;
+    for (u32 q = 0; q < p; ++q) before += raw_all[(size_t)q * bstride + b + 1] - raw_all[(size_t)q * bstride + b];
+    const u32 cnt = raw_all[(size_t)p * bstride + b + 1] - raw_all[(size_t)p * bstride + b];
+    const size_t src = (size_t)p * lstride + pos_all[(size_t)p * bstride + b];
+    const u32 dst = blk_pos[b] + before;
+    const u32 ro = rank_off[p], bo = big_off[p];
+    for (u32 i = threadIdx.x; i < cnt; i += blockDim.x) {
+        brk[dst + i] = brk_all[src + i] + ro;
+        u32 inf = info_all[src + i];
+        if (inf >= BIG) inf = BIG | ((inf & ~BIG) + bo);
+        info[dst + i] = inf;
+        if (W) bw[dst + i] = bw_all[src + i];
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // stage 2: the join kernel
 // ------------------------------------------------------------------------------------
@@ -916,6 +1004,11 @@ struct ksp_engine {
     u64 n_kept = 0;               // entries whose key is held by >= 2 sources (the others are pruned)
     bool weighted = false;
     bool built = false;
+    u32 nparts = 1, part_id = 0;  // key-range slice mode (multi-GPU build)
+    u64 max_key = 0;
+    bool have_max_key = false;
+    bool slice_ready = false;
+    u64 slice_hdr[4] = {0, 0, 0, 0};   // padded length, distinct keys (U), big postings, block keys
     u32 ncell = ksp::NP;          // fine rank cells per block (power of two)
     bool use_cells = true;        // rank-aligned cell join (KSP_JOIN=window selects the sliding-window merge)
     bool full_sort = false;       // keys defeat the 32-bit prefix sort: use all bits
@@ -925,7 +1018,7 @@ struct ksp_engine {
     std::vector<u32> h_blk_off;   // distinct-key offsets of the block lists (host copy)
     std::vector<u32> h_blk_max;   // per block: largest per-source k-mer count / weight sum
     // workspace
-    ksp::Buf d_off, KA, KB, VA, VB, R1, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, blk_max, part, scalars, count, tailbuf;
+    ksp::Buf d_off, KA, KB, VA, VB, R1, FK, FT, asm_small, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, blk_max, part, scalars, count, tailbuf;
     u32 slots = 0;                // workgroups of k_join the chip holds at once (occupancy x CUs)
     unsigned long long* h_count = nullptr;   // pinned
     u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
@@ -956,13 +1049,14 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if ((rc = e->blk_pos.ensure(((size_t)nb + 2) * 4))) return rc;
     if ((rc = e->part.ensure(((size_t)nb + 1) * ((size_t)e->ncell + 1) * 4))) return rc;
     if ((rc = e->blk_max.ensure(((size_t)nb + 2) * 4))) return rc;
-    if ((rc = e->scalars.ensure(64))) return rc;
+    if ((rc = e->scalars.ensure(128))) return rc;
 
     u64* KA = e->KA.as<u64>();
     V* VA = e->VA.as<V>();
     V* VB = e->VB.as<V>();
     u64* d_off = e->d_off.as<u64>();
-    u64* scal = e->scalars.as<u64>();   // [0] max key, [1] Ktot, [2] U, [3] padded length
+    u64* scal = e->scalars.as<u64>();   // [0] max key, [1] Ktot, [2] U, [3] padded length, [4] overflow, [5] fix count,
+                                        // [6] kept entries, [7] big postings, [8] entries of the slice
     u32* blk_raw = e->blk_raw.as<u32>();
     u32* blk_pos = e->blk_pos.as<u32>();
     const unsigned bs = 256;
@@ -970,12 +1064,13 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     // key range (one 8-byte D2H, unless the caller passed key_bits)
     size_t tb = 0;
     if (e->key_bits <= 0) {
-        KSP_HIP(rocprim::reduce(nullptr, tb, d_keys, scal, (u64)0, n, rocprim::maximum<u64>(), st));
-        if ((rc = e->tmp.ensure(tb))) return rc;
-        KSP_HIP(rocprim::reduce(e->tmp.p, tb, d_keys, scal, (u64)0, n, rocprim::maximum<u64>(), st));
+        KSP_HIP(hipMemsetAsync(scal, 0, 8, st));
+        hipLaunchKernelGGL(k_max_last, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_keys, d_off, (unsigned long long*)scal, N);
         KSP_HIP(hipMemcpyAsync(e->h_scal, scal, 8, hipMemcpyDeviceToHost, st));
         KSP_HIP(hipStreamSynchronize(st));
         u64 mx = e->h_scal[0];
+        e->max_key = mx;
+        e->have_max_key = true;
         int bits = 1;
         while (bits < 64 && (mx >> bits)) ++bits;
         e->key_bits = bits;
@@ -985,8 +1080,44 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     while ((1u << bbits) < nb) ++bbits;
 
     if (W) KSP_HIP(hipMemsetAsync(e->blk_max.p, 0, ((size_t)nb + 1) * 4, st));
-    hipLaunchKernelGGL((k_tag<W>), dim3(N), dim3(256), 0, st, d_off, d_w, W ? nullptr : (u32*)VA,
-                       W ? (u64*)VA : nullptr, e->blk_max.as<u32>());
+    if (W || e->nparts == 1)   // (weighted slices still need the per-source weight sums of all entries)
+        hipLaunchKernelGGL((k_tag<W>), dim3(N), dim3(256), 0, st, d_off, d_w, W ? nullptr : (u32*)VA,
+                           W ? (u64*)VA : nullptr, e->blk_max.as<u32>());
+    // slice mode (multi-GPU build): keep only the entries of this part's key range — one contiguous
+    // sub-run per (sorted) source, so the cost is proportional to the slice, not to the sketch set
+    const u64* keys_in = d_keys;
+    const V* tags_in = VA;
+    u64 nw = n;
+    if (e->nparts > 1) {
+        // equal shares of [0, largest key] (or of [0, 2^key_bits) when the caller fixed key_bits)
+        const unsigned __int128 span = e->have_max_key ? (unsigned __int128)e->max_key + 1
+                                       : kbits >= 64   ? ((unsigned __int128)1 << 64)
+                                                       : ((unsigned __int128)1 << kbits);
+        const u64 lo = (u64)((span * e->part_id) / e->nparts);
+        const u64 hi = (u64)((span * (e->part_id + 1)) / e->nparts - 1);
+        u32* first = (u32*)e->KB.p;                 // N
+        u32* cnt = (u32*)e->KB.p + (N + 2);         // N
+        u32* fpos = (u32*)e->KB.p + 2 * ((size_t)N + 2);   // N   (KB holds 2(n+4) u32 >= 3(N+2) whenever n >= 2N; checked below)
+        if ((rc = e->KB.ensure(std::max<size_t>((n + 4) * 8, 3 * ((size_t)N + 2) * 4)))) return rc;
+        first = (u32*)e->KB.p; cnt = first + (N + 2); fpos = first + 2 * ((size_t)N + 2);
+        hipLaunchKernelGGL(k_range_bounds, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_keys, d_off, lo, hi, first, cnt, N);
+        tb = 0;
+        KSP_HIP(rocprim::exclusive_scan(nullptr, tb, cnt, fpos, (u32)0, (size_t)N, rocprim::plus<u32>(), st));
+        if ((rc = e->tmp.ensure(tb))) return rc;
+        KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, cnt, fpos, (u32)0, (size_t)N, rocprim::plus<u32>(), st));
+        hipLaunchKernelGGL(k_range_total, dim3(1), dim3(64), 0, st, fpos, cnt, scal, N);
+        KSP_HIP(hipMemcpyAsync(e->h_scal + 8, scal + 8, 8, hipMemcpyDeviceToHost, st));
+        KSP_HIP(hipStreamSynchronize(st));
+        nw = e->h_scal[8];
+        if ((rc = e->FK.ensure((nw + 4) * 8))) return rc;
+        if ((rc = e->FT.ensure((nw + 4) * sizeof(V)))) return rc;
+        hipLaunchKernelGGL((k_range_copy<V, W>), dim3(N), dim3(128), 0, st, d_keys, d_w, d_off, first, cnt, fpos,
+                           e->FK.as<u64>(), e->FT.as<V>());
+        keys_in = e->FK.as<u64>();
+        tags_in = e->FT.as<V>();
+    }
+    e->n_kept = 0;
+    if (nw == 0) return KSP_OK;   // (slice mode only) no key of this range
     // sort 1: all entries by the top 32 significant key bits (payload = tag [+weight]):
     // d_keys,VA -> KA,VB; then order the rare mixed runs by the full key (k_fix_runs)
     // (rocPRIM 4.2 / ROCm 7.2 mis-sorts 64-bit keys on any bit range [b > 0, 64) below ~1M items —
@@ -996,19 +1127,19 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     u32* d_ovf = (u32*)(scal + 4);   // set by k_fix_runs when a run is too long; checked at the end of the build
     KSP_HIP(hipMemsetAsync(d_ovf, 0, 8, st));
     tb = 0;
-    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_keys, KA, VA, VB, n, shift, kbits, st));
+    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, KA, tags_in, VB, nw, shift, kbits, st));
     if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, d_keys, KA, VA, VB, n, shift, kbits, st));
+    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, keys_in, KA, tags_in, VB, nw, shift, kbits, st));
     if (shift > 0) {
         // KB is free until the rank scan: use it for the work list of mixed runs
         u32* fixlist = (u32*)e->KB.p;
-        const u32 fixcap = (u32)std::min<u64>(2 * n, 0x7FFFFFFFull);   // positions are < 2^30 (DROP bit is free)
+        const u32 fixcap = (u32)std::min<u64>(2 * nw, 0x7FFFFFFFull);   // positions are < 2^30 (DROP bit is free)
         u32* d_cnt = (u32*)(scal + 5);
         KSP_HIP(hipMemsetAsync(d_cnt, 0, 8, st));
-        hipLaunchKernelGGL(k_find_mixed, dim3(grid_for(n, 4096)), dim3(1024), 0, st, KA, n, shift, fixlist, d_cnt,
+        hipLaunchKernelGGL(k_find_mixed, dim3(grid_for(nw, 4096)), dim3(1024), 0, st, KA, nw, shift, fixlist, d_cnt,
                            fixcap, d_ovf);
         hipLaunchKernelGGL(k_mark_first, dim3(4096), dim3(64), 0, st, KA, shift, fixlist, d_cnt, fixcap, d_ovf);
-        hipLaunchKernelGGL((k_fix_runs<V>), dim3(4096), dim3(64), 0, st, KA, VB, n, shift, fixlist, d_cnt, fixcap,
+        hipLaunchKernelGGL((k_fix_runs<V>), dim3(4096), dim3(64), 0, st, KA, VB, nw, shift, fixlist, d_cnt, fixcap,
                            d_ovf);
     }
     // singleton pruning + dense ranks of the kept keys (packed counters, one scan):  KA,VB -> R1 (ranks), VA (tags)
@@ -1016,13 +1147,13 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     u64* ps = (u64*)e->KB.p;               // n packed prefix sums
     u32* rank1 = e->R1.as<u32>();
     {
-        auto pf = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u64>(0), PruneFn{KA, n});
+        auto pf = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u64>(0), PruneFn{KA, nw});
         tb = 0;
-        KSP_HIP(rocprim::inclusive_scan(nullptr, tb, pf, ps, n, rocprim::plus<u64>(), st));
+        KSP_HIP(rocprim::inclusive_scan(nullptr, tb, pf, ps, nw, rocprim::plus<u64>(), st));
         if ((rc = e->tmp.ensure(tb))) return rc;
-        KSP_HIP(rocprim::inclusive_scan(e->tmp.p, tb, pf, ps, n, rocprim::plus<u64>(), st));
+        KSP_HIP(rocprim::inclusive_scan(e->tmp.p, tb, pf, ps, nw, rocprim::plus<u64>(), st));
     }
-    hipLaunchKernelGGL((k_prune_scatter<V>), dim3(grid_for(n, bs)), dim3(bs), 0, st, VB, ps, VA, rank1, scal, n);
+    hipLaunchKernelGGL((k_prune_scatter<V>), dim3(grid_for(nw, bs)), dim3(bs), 0, st, VB, ps, VA, rank1, scal, nw);
     KSP_HIP(hipMemcpyAsync(e->h_scal + 6, scal + 6, 8, hipMemcpyDeviceToHost, st));
     KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
     const u64 m = e->h_scal[6];
@@ -1057,6 +1188,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     KSP_HIP(rocprim::exclusive_scan(nullptr, tb, mmsz, mmoff, (u32)0, m, rocprim::plus<u32>(), st));
     if ((rc = e->tmp.ensure(tb))) return rc;
     KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, mmsz, mmoff, (u32)0, m, rocprim::plus<u32>(), st));
+    hipLaunchKernelGGL(k_nbig, dim3(1), dim3(64), 0, st, mmsz, mmoff, scal);
     hipLaunchKernelGGL((k_emit_info<V, W>), dim3(grid_for(m, bs)), dim3(bs), 0, st, estart, mmoff, scal, T,
                        blk_raw, blk_pos, e->info.as<u32>(), e->mm.as<uint4>(), W ? e->bw.as<u32>() : nullptr);
     // rank-range partition of every block list
@@ -1095,7 +1227,7 @@ int ksp_engine_create(int device, ksp_engine** out) {
     ksp_engine* e = new ksp_engine();
     e->device = device;
     KSP_HIP(hipHostMalloc((void**)&e->h_count, 64));
-    KSP_HIP(hipHostMalloc((void**)&e->h_scal, 64));
+    KSP_HIP(hipHostMalloc((void**)&e->h_scal, 128));
     for (int i = 0; i < 4; ++i) KSP_HIP(hipEventCreate(&e->ev[i]));
     *out = e;
     return KSP_OK;
@@ -1104,7 +1236,7 @@ int ksp_engine_create(int device, ksp_engine** out) {
 void ksp_engine_destroy(ksp_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
-    ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->tmp, &e->bkeys, &e->info,
+    ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
@@ -1113,23 +1245,45 @@ void ksp_engine_destroy(ksp_engine* e) {
     delete e;
 }
 
-int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights,
-                            const uint64_t* h_offsets, uint32_t n_sources, int key_bits, void* stream) {
-    if (!e || !h_offsets) { set_error("build_blocks: NULL argument"); return KSP_E_ARG; }
-    hipStream_t st = (hipStream_t)stream;
+// host-side bookkeeping once the full block lists sit in the engine's arrays
+static int finish_build(ksp_engine* e) {
+    e->st.key_bits = e->key_bits;
+    if (e->weighted)
+        KSP_HIP(hipMemcpy(e->h_blk_max.data(), e->blk_max.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
+    {
+        u32 big_blocks = 0;
+        for (u32 b = 0; b < e->nb; ++b) big_blocks += e->h_blk_max[b] >= 65536u;
+        e->need32 = big_blocks >= 1;   // a big block pairs with itself (diagonal tile) at least
+    }
+    e->h_blk_off.resize((size_t)e->nb + 1);
+    KSP_HIP(hipMemcpy(e->h_blk_off.data(), e->blk_raw.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
+    e->st.n_block_keys = e->h_blk_off[e->nb];
+    e->built = true;
+    return KSP_OK;
+}
+
+// common front end of build_blocks / build_slice
+static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights, const uint64_t* h_offsets,
+                        uint32_t n_sources, int key_bits, u32 part, u32 nparts, hipStream_t st) {
+    if (!e || !h_offsets) { set_error("build: NULL argument"); return KSP_E_ARG; }
+    if (nparts == 0 || part >= nparts) { set_error("build: bad part / nparts"); return KSP_E_ARG; }
     KSP_HIP(hipSetDevice(e->device));
     e->built = false;
+    e->slice_ready = false;
     for (u32 s = 0; s < n_sources; ++s)
-        if (h_offsets[s + 1] < h_offsets[s]) { set_error("build_blocks: offsets not monotone"); return KSP_E_ARG; }
+        if (h_offsets[s + 1] < h_offsets[s]) { set_error("build: offsets not monotone"); return KSP_E_ARG; }
     const u64 n = n_sources ? h_offsets[n_sources] - h_offsets[0] : 0;
-    if (n_sources && h_offsets[0] != 0) { set_error("build_blocks: offsets[0] must be 0"); return KSP_E_ARG; }
-    if (n >= (1ull << 30)) { set_error("build_blocks: more than 2^30 key entries per call"); return KSP_E_LIMIT; }
-    if (n && !d_keys) { set_error("build_blocks: d_keys is NULL"); return KSP_E_ARG; }
+    if (n_sources && h_offsets[0] != 0) { set_error("build: offsets[0] must be 0"); return KSP_E_ARG; }
+    if (n >= (1ull << 30)) { set_error("build: more than 2^30 key entries per call"); return KSP_E_LIMIT; }
+    if (n && !d_keys) { set_error("build: d_keys is NULL"); return KSP_E_ARG; }
     e->n_sources = n_sources;
     e->n_entries = n;
     e->nb = (n_sources + TB - 1) / TB;
     e->weighted = d_weights != nullptr;
     e->key_bits = key_bits;
+    e->have_max_key = false;
+    e->nparts = nparts;
+    e->part_id = part;
     e->h_off.assign(h_offsets, h_offsets + n_sources + 1);
     if (std::getenv("KSP_FULL_SORT")) e->full_sort = true;   // diagnostic: sort on all key bits
     e->st = ksp_stats{};
@@ -1139,11 +1293,10 @@ int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_
     e->st.n_tiles = (u64)e->nb * (e->nb + 1) / 2;
     e->st.weighted = e->weighted;
     e->n_kept = 0;
-    if (n == 0 || e->nb == 0) {   // nothing can intersect
-        e->built = true;
-        e->st.key_bits = 0;
-        return KSP_OK;
-    }
+    e->h_blk_off.assign((size_t)e->nb + 1, 0);
+    e->h_blk_max.assign((size_t)e->nb + 1, 0);
+    std::memset(e->slice_hdr, 0, sizeof e->slice_hdr);
+    if (n == 0 || e->nb == 0) return KSP_OK;   // nothing can intersect
     int rc;
     if ((rc = e->d_off.ensure(((size_t)n_sources + 1) * 8))) return rc;
     KSP_HIP(hipEventRecord(e->ev[0], st));
@@ -1162,7 +1315,6 @@ int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_
         e->use_cells = !(jm && std::string(jm) == "window");
     }
     if ((rc = e->blk_max.ensure(((size_t)e->nb + 2) * 4))) return rc;
-    e->h_blk_max.assign((size_t)e->nb + 1, 0);
     if (!e->weighted) {   // raw hashes: a source's bound is its k-mer count
         for (u32 s = 0; s < n_sources; ++s) {
             u64 c = h_offsets[s + 1] - h_offsets[s];
@@ -1175,7 +1327,7 @@ int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_
         rc = e->weighted ? build_impl<true>(e, d_keys, d_weights, st) : build_impl<false>(e, d_keys, d_weights, st);
         if (rc) return rc;
         KSP_HIP(hipEventRecord(e->ev[1], st));
-        KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 32, hipMemcpyDeviceToHost, st));
+        KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 64, hipMemcpyDeviceToHost, st));
         KSP_HIP(hipStreamSynchronize(st));
         if ((u32)e->h_scal[4] == 0) break;
         // pathological key distribution (thousands of distinct keys share their top 32 bits):
@@ -1184,26 +1336,146 @@ int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_
     }
     KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
     e->st.key_bits = e->key_bits;
-    if (e->n_kept == 0) {   // no key is held by two sources: every pair count is zero
+    return KSP_OK;
+}
+
+int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights,
+                            const uint64_t* h_offsets, uint32_t n_sources, int key_bits, void* stream) {
+    int rc = build_common(e, d_keys, d_weights, h_offsets, n_sources, key_bits, 0, 1, (hipStream_t)stream);
+    if (rc) return rc;
+    if (e->n_entries == 0 || e->nb == 0 || e->n_kept == 0) {   // no key is held by two sources: all counts are zero
         e->st.n_block_keys = 0;
-        e->h_blk_off.assign((size_t)e->nb + 1, 0);
         e->need32 = false;
         e->built = true;
         return KSP_OK;
     }
-    e->st.n_block_keys = e->h_scal[1];
-    if (e->weighted)
-        KSP_HIP(hipMemcpy(e->h_blk_max.data(), e->blk_max.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
-    {
-        u32 big_blocks = 0;
-        for (u32 b = 0; b < e->nb; ++b) big_blocks += e->h_blk_max[b] >= 65536u;
-        e->need32 = big_blocks >= 1;   // a big block pairs with itself (diagonal tile) at least
+    return finish_build(e);
+}
+
+// ---- key-range slices: build one part, export it, assemble all parts ----------------------
+int ksp_engine_build_slice(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights,
+                           const uint64_t* h_offsets, uint32_t n_sources, int key_bits, uint32_t part,
+                           uint32_t nparts, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int rc = build_common(e, d_keys, d_weights, h_offsets, n_sources, key_bits, part, nparts, st);
+    if (rc) return rc;
+    if (e->n_entries == 0 || e->nb == 0) { e->slice_ready = true; return KSP_OK; }
+    if (e->n_kept == 0) {
+        // empty slice: valid (all-pad) lists so that export / assemble need no special case
+        if ((rc = e->blk_raw.ensure(((size_t)e->nb + 2) * 4))) return rc;
+        KSP_HIP(hipMemsetAsync(e->blk_raw.p, 0, ((size_t)e->nb + 2) * 4, st));
+        hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, e->blk_raw.as<u32>(), e->blk_pos.as<u32>(),
+                           e->scalars.as<u64>(), e->nb);
+        const u64 lpad = (u64)e->nb * (WIN + 4) + 4 * WIN;
+        hipLaunchKernelGGL(k_fill, dim3(grid_for(lpad, 256)), dim3(256), 0, st, e->bkeys.as<u32>(), PAD, lpad);
+        KSP_HIP(hipMemcpyAsync(e->h_scal + 3, e->scalars.as<u64>() + 3, 8, hipMemcpyDeviceToHost, st));
+        KSP_HIP(hipStreamSynchronize(st));
+        e->slice_hdr[0] = e->h_scal[3];
+        e->slice_hdr[1] = e->slice_hdr[2] = e->slice_hdr[3] = 0;
+    } else {
+        e->slice_hdr[0] = e->h_scal[3];   // padded length
+        e->slice_hdr[1] = e->h_scal[2];   // distinct keys (U)
+        e->slice_hdr[2] = e->h_scal[7];   // big postings
+        e->slice_hdr[3] = e->h_scal[1];   // block keys
     }
-    e->h_blk_off.resize((size_t)e->nb + 1);
-    KSP_HIP(hipMemcpy(e->h_blk_off.data(), e->blk_raw.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
-    e->st.key_bits = e->key_bits;
-    e->built = true;
+    e->slice_ready = true;
     return KSP_OK;
+}
+
+int ksp_engine_slice_sizes(const ksp_engine* e, uint64_t out[4]) {
+    if (!e || !out) return KSP_E_ARG;
+    if (!e->slice_ready) { set_error("slice_sizes: build_slice has not been run"); return KSP_E_ARG; }
+    for (int i = 0; i < 4; ++i) out[i] = e->slice_hdr[i];
+    return KSP_OK;
+}
+
+int ksp_engine_slice_export(ksp_engine* e, uint32_t* d_brk, uint32_t* d_info, uint32_t* d_bw, uint32_t* d_blk_raw,
+                            uint32_t* d_blk_pos, void* d_big, void* stream) {
+    if (!e || !e->slice_ready) { set_error("slice_export: build_slice has not been run"); return KSP_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    KSP_HIP(hipSetDevice(e->device));
+    if (e->n_entries == 0 || e->nb == 0) return KSP_OK;
+    const size_t L = (size_t)e->slice_hdr[0];
+    KSP_HIP(hipMemcpyAsync(d_brk, e->bkeys.p, L * 4, hipMemcpyDeviceToDevice, st));
+    if (e->slice_hdr[3]) {
+        KSP_HIP(hipMemcpyAsync(d_info, e->info.p, L * 4, hipMemcpyDeviceToDevice, st));
+        if (e->weighted && d_bw) KSP_HIP(hipMemcpyAsync(d_bw, e->bw.p, L * 4, hipMemcpyDeviceToDevice, st));
+    }
+    KSP_HIP(hipMemcpyAsync(d_blk_raw, e->blk_raw.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToDevice, st));
+    KSP_HIP(hipMemcpyAsync(d_blk_pos, e->blk_pos.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToDevice, st));
+    if (e->slice_hdr[2]) KSP_HIP(hipMemcpyAsync(d_big, e->mm.p, (size_t)e->slice_hdr[2] * 16, hipMemcpyDeviceToDevice, st));
+    KSP_HIP(hipStreamSynchronize(st));
+    return KSP_OK;
+}
+
+int ksp_engine_assemble(ksp_engine* e, uint32_t nparts, const uint64_t* h_sizes /* nparts x 4 */,
+                        const uint32_t* d_brk_all, const uint32_t* d_info_all, const uint32_t* d_bw_all,
+                        uint64_t lstride, const uint32_t* d_blk_raw_all, const uint32_t* d_blk_pos_all,
+                        const void* d_big_all, uint64_t bigstride, void* stream) {
+    if (!e || !h_sizes || nparts == 0) { set_error("assemble: bad argument"); return KSP_E_ARG; }
+    if (!e->slice_ready) { set_error("assemble: build_slice must run on this engine first (it sets the geometry)"); return KSP_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    KSP_HIP(hipSetDevice(e->device));
+    e->built = false;
+    if (e->n_entries == 0 || e->nb == 0) { e->built = true; return KSP_OK; }
+    const u32 nb = e->nb;
+    u64 ktot = 0, utot = 0, bigtot = 0;
+    std::vector<u32> off(2 * (size_t)nparts);
+    for (u32 p = 0; p < nparts; ++p) {
+        off[p] = (u32)utot;             // rank offset of part p
+        off[nparts + p] = (u32)bigtot;  // mask index offset of part p
+        utot += h_sizes[4 * p + 1];
+        bigtot += h_sizes[4 * p + 2];
+        ktot += h_sizes[4 * p + 3];
+    }
+    if (utot >= (1ull << 30)) { set_error("assemble: more than 2^30 distinct keys"); return KSP_E_LIMIT; }
+    e->n_kept = ktot;   // (>0 iff some key is shared)
+    if (ktot == 0) {
+        e->st.n_block_keys = 0;
+        e->need32 = false;
+        e->h_blk_off.assign((size_t)nb + 1, 0);
+        e->built = true;
+        return KSP_OK;
+    }
+    int rc;
+    const u64 lmax = ktot + (u64)nb * (WIN + 4) + 4 * WIN;
+    if ((rc = e->bkeys.ensure(lmax * 4))) return rc;
+    if ((rc = e->info.ensure(lmax * 4))) return rc;
+    if (e->weighted && (rc = e->bw.ensure(lmax * 4))) return rc;
+    if ((rc = e->mm.ensure((bigtot + 16) * 16))) return rc;
+    if ((rc = e->asm_small.ensure(off.size() * 4))) return rc;
+    KSP_HIP(hipEventRecord(e->ev[0], st));
+    KSP_HIP(hipMemcpyAsync(e->asm_small.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, st));
+    u64* scal = e->scalars.as<u64>();
+    hipLaunchKernelGGL(k_asm_counts, dim3(1), dim3(64), 0, st, d_blk_raw_all, nb + 1, nparts, nb, e->blk_raw.as<u32>());
+    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), scal, nb);
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(lmax, 256)), dim3(256), 0, st, e->bkeys.as<u32>(), PAD, lmax);
+    const u32* roff = e->asm_small.as<u32>();
+    if (e->weighted)
+        hipLaunchKernelGGL((k_asm_copy<true>), dim3(nb, nparts), dim3(256), 0, st, d_brk_all, d_info_all, d_bw_all,
+                           (size_t)lstride, d_blk_raw_all, d_blk_pos_all, nb + 1, roff, roff + nparts,
+                           e->blk_pos.as<u32>(), e->bkeys.as<u32>(), e->info.as<u32>(), e->bw.as<u32>());
+    else
+        hipLaunchKernelGGL((k_asm_copy<false>), dim3(nb, nparts), dim3(256), 0, st, d_brk_all, d_info_all, d_bw_all,
+                           (size_t)lstride, d_blk_raw_all, d_blk_pos_all, nb + 1, roff, roff + nparts,
+                           e->blk_pos.as<u32>(), e->bkeys.as<u32>(), e->info.as<u32>(), (u32*)nullptr);
+    for (u32 p = 0; p < nparts; ++p)
+        if (h_sizes[4 * p + 2])
+            KSP_HIP(hipMemcpyAsync((char*)e->mm.p + (size_t)off[nparts + p] * 16,
+                                   (const char*)d_big_all + (size_t)p * bigstride * 16, (size_t)h_sizes[4 * p + 2] * 16,
+                                   hipMemcpyDeviceToDevice, st));
+    e->h_scal[1] = ktot;
+    e->h_scal[2] = utot;
+    KSP_HIP(hipMemcpyAsync(scal + 1, e->h_scal + 1, 16, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_cidx, dim3(grid_for((u64)nb * (e->ncell + 1), 256)), dim3(256), 0, st, e->bkeys.as<u32>(),
+                       e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), scal, e->part.as<u32>(), nb, e->ncell);
+    KSP_HIP(hipGetLastError());
+    KSP_HIP(hipEventRecord(e->ev[1], st));
+    KSP_HIP(hipStreamSynchronize(st));
+    float ms = 0;
+    KSP_HIP(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
+    e->st.ms_build += ms;   // slice build + assemble
+    return finish_build(e);
 }
 
 uint64_t ksp_engine_num_tiles(const ksp_engine* e) { return e ? (u64)e->nb * (e->nb + 1) / 2 : 0; }

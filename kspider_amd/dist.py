@@ -34,6 +34,62 @@ def tile_of_pair(a: np.ndarray, b: np.ndarray, n_sources: int, tb: int = 128) ->
     return i * nb - i * (i - 1) // 2 + (j - i)
 
 
+def build_blocks_sharded(eng, d_keys_ptr: int, h_offsets: np.ndarray, world_size: int, rank: int, device,
+                         d_weights_ptr: int = 0, stream: int = 0, group=None):
+    """Stage 1 sharded over the ranks (every rank holds the full sketch set).
+
+    Rank r builds the block-list slices of its 1/world share of the hash range
+    (`Engine.build_slice`), the slices are all-gathered (RCCL `all_gather_into_tensor`; host tensors
+    with gloo), and every rank assembles the full lists (`Engine.assemble`).  With world_size 1 this
+    is a plain `build_blocks`.  Returns the bytes this rank received in the exchange.
+    """
+    if world_size == 1:
+        eng.build_blocks(d_keys_ptr, h_offsets, d_weights_ptr=d_weights_ptr, stream=stream)
+        return 0
+    eng.build_slice(d_keys_ptr, h_offsets, rank, world_size, d_weights_ptr=d_weights_ptr, stream=stream)
+    on_gpu = dist.get_backend(group) == "nccl"
+    comm_dev = device if on_gpu else torch.device("cpu")
+    mine = torch.from_numpy(eng.slice_sizes().astype(np.int64)).to(comm_dev)
+    all_sz = torch.zeros(4 * world_size, dtype=torch.int64, device=comm_dev)
+    if on_gpu:
+        dist.all_gather_into_tensor(all_sz, mine, group=group)
+    else:
+        dist.all_gather(list(all_sz.split(4)), mine, group=group)
+    sizes = all_sz.cpu().numpy().astype(np.uint64)
+    nb = (len(h_offsets) - 1 + 127) // 128
+    lstride = max(4, int(sizes[0::4].max()))
+    bigstride = max(1, int(sizes[2::4].max()))
+    weighted = d_weights_ptr != 0
+
+    def alloc(cols):
+        return torch.zeros((world_size, cols), dtype=torch.int32, device=device)
+
+    brk_all, info_all = alloc(lstride), alloc(lstride)
+    bw_all = alloc(lstride) if weighted else None
+    raw_all, pos_all, big_all = alloc(nb + 1), alloc(nb + 1), alloc(4 * bigstride)
+    loc = [torch.zeros(lstride, dtype=torch.int32, device=device), torch.zeros(lstride, dtype=torch.int32, device=device),
+           torch.zeros(lstride, dtype=torch.int32, device=device) if weighted else None,
+           torch.zeros(nb + 1, dtype=torch.int32, device=device), torch.zeros(nb + 1, dtype=torch.int32, device=device),
+           torch.zeros(4 * bigstride, dtype=torch.int32, device=device)]
+    eng.slice_export(loc[0].data_ptr(), loc[1].data_ptr(), loc[2].data_ptr() if weighted else 0, loc[3].data_ptr(),
+                     loc[4].data_ptr(), loc[5].data_ptr(), stream=stream)
+    received = 0
+    for out, src in ((brk_all, loc[0]), (info_all, loc[1]), (bw_all, loc[2]), (raw_all, loc[3]), (pos_all, loc[4]),
+                     (big_all, loc[5])):
+        if out is None:
+            continue
+        if on_gpu:
+            dist.all_gather_into_tensor(out.view(-1), src, group=group)
+        else:   # gloo: through host memory (test hook)
+            parts = [torch.zeros(src.shape, dtype=src.dtype) for _ in range(world_size)]
+            dist.all_gather(parts, src.cpu(), group=group)
+            out.copy_(torch.stack(parts).to(device))
+        received += out.numel() * 4 * (world_size - 1) // world_size
+    eng.assemble(sizes, brk_all.data_ptr(), info_all.data_ptr(), bw_all.data_ptr() if weighted else 0, lstride,
+                 raw_all.data_ptr(), pos_all.data_ptr(), big_all.data_ptr(), bigstride, stream=stream)
+    return received
+
+
 def gather_edges(local: torch.Tensor, dst: int = 0, group=None) -> torch.Tensor | None:
     """Gather variable-length edge lists ([n, 16] uint8 tensors) to rank `dst`.
 

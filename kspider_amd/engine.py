@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "ksp_engine_get_stats", "ksp_device_malloc", "ksp_device_free", "ksp_memcpy_h2d", "ksp_memcpy_d2h",
     "ksp_pairwise_host", "ksp_free", "kspider_pairwise", "ksp_index_info", "ksp_format_float",
     "kspider_pairwise_sigs", "kspider_pairwise_bins",
+    "ksp_engine_build_slice", "ksp_engine_slice_sizes", "ksp_engine_slice_export", "ksp_engine_assemble",
 ]
 
 
@@ -71,6 +72,14 @@ def lib():
         L.ksp_engine_join.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
                                       ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]
         L.ksp_engine_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
+        L.ksp_engine_build_slice.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                             ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32,
+                                             ctypes.c_void_p]
+        L.ksp_engine_slice_sizes.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        L.ksp_engine_slice_export.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 7
+        L.ksp_engine_assemble.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
         L.ksp_device_malloc.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
         L.ksp_device_free.argtypes = [ctypes.c_void_p]
         L.ksp_memcpy_h2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
@@ -173,6 +182,33 @@ class Engine:
         self._off = h_offsets
         _check(lib().ksp_engine_build_blocks(self._h, d_keys_ptr or None, d_weights_ptr or None,
                                              h_offsets.ctypes.data, h_offsets.size - 1, key_bits, stream or None))
+
+    # ---- key-range sharded stage 1 (multi-GPU) ------------------------------------------------
+    def build_slice(self, d_keys_ptr: int, h_offsets: np.ndarray, part: int, nparts: int, d_weights_ptr: int = 0,
+                    key_bits: int = 0, stream: int = 0):
+        h_offsets = np.ascontiguousarray(h_offsets, dtype=np.uint64)
+        self._off = h_offsets
+        _check(lib().ksp_engine_build_slice(self._h, d_keys_ptr or None, d_weights_ptr or None,
+                                            h_offsets.ctypes.data, h_offsets.size - 1, key_bits, part, nparts,
+                                            stream or None))
+
+    def slice_sizes(self) -> np.ndarray:
+        out = (ctypes.c_uint64 * 4)()
+        _check(lib().ksp_engine_slice_sizes(self._h, out))
+        return np.array(list(out), dtype=np.uint64)
+
+    def slice_export(self, d_brk: int, d_info: int, d_bw: int, d_blk_raw: int, d_blk_pos: int, d_big: int,
+                     stream: int = 0):
+        _check(lib().ksp_engine_slice_export(self._h, d_brk or None, d_info or None, d_bw or None, d_blk_raw or None,
+                                             d_blk_pos or None, d_big or None, stream or None))
+
+    def assemble(self, h_sizes: np.ndarray, d_brk_all: int, d_info_all: int, d_bw_all: int, lstride: int,
+                 d_blk_raw_all: int, d_blk_pos_all: int, d_big_all: int, bigstride: int, stream: int = 0):
+        h_sizes = np.ascontiguousarray(h_sizes, dtype=np.uint64)
+        nparts = h_sizes.size // 4
+        _check(lib().ksp_engine_assemble(self._h, nparts, h_sizes.ctypes.data, d_brk_all or None, d_info_all or None,
+                                         d_bw_all or None, lstride, d_blk_raw_all or None, d_blk_pos_all or None,
+                                         d_big_all or None, bigstride, stream or None))
 
     @property
     def num_tiles(self) -> int:
