@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tests/_prof_bench.sh <tag>   — rocprofv3 kernel stats + HBM traffic counters of `python3 bench.py`
+# usage: tools/prof_bench.sh <tag>   — rocprofv3 kernel stats + HBM traffic counters of `python3 bench.py`
 set -e
 TAG=$1
 R=$GRAFT_REPO_ROOT
@@ -13,7 +13,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARG
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc1 -- python3 $ARGS > /dev/null 2> $OUT/pmc1.err
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD --output-format csv -d $OUT/pmc2 -- python3 $ARGS > /dev/null 2> $OUT/pmc2.err
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/pmc3 -- python3 $ARGS > /dev/null 2> $OUT/pmc3.err || true
-python3 $R/tests/_pmc_summary.py $OUT all > $OUT/summary.txt 2>&1 || true
+python3 $R/tools/pmc_summary.py $OUT all > $OUT/summary.txt 2>&1 || true
 # keep only the small artefacts
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 du -sh $OUT
