@@ -1516,7 +1516,6 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     e->st.last_tiles = 0; e->st.last_pairs = 0; e->st.last_edges = 0; e->st.last_stream_bytes = 0; e->st.ms_join = 0;
     if (tile_begin >= tile_end || e->n_entries == 0 || e->n_kept == 0) return KSP_OK;
     if (capacity && !d_edges) { set_error("join: d_edges is NULL"); return KSP_E_ARG; }
-    if (tile_end - tile_begin > 0x7FFFFFFFull) { set_error("join: more than 2^31 tiles in one launch"); return KSP_E_LIMIT; }
     int rc;
     if ((rc = e->count.ensure(64))) return rc;
     JoinArgs a;
@@ -1540,7 +1539,13 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     KSP_HIP(hipEventRecord(e->ev[2], st));
     dim3 block(JW * 64);
     a.blk_max = e->blk_max.as<u32>();
-    const u32 ntiles = (u32)(tile_end - tile_begin);
+    // HIP caps a launch at 2^32 threads: at most 4 Mi workgroups of 512 threads per launch (a larger grid
+    // silently runs only part of its blocks — seen with 30.5 M tiles on MI355X / ROCm 7.2)
+    const u64 kMaxTilesPerLaunch = 4ull << 20;
+    for (u64 chunk_begin = tile_begin; chunk_begin < tile_end; chunk_begin += kMaxTilesPerLaunch) {
+    const u64 chunk_end = std::min(tile_end, chunk_begin + kMaxTilesPerLaunch);
+    a.tile_begin = chunk_begin;
+    const u32 ntiles = (u32)(chunk_end - chunk_begin);
     // Tile splitting for small launches: when there are fewer tiles than workgroup slots on the chip,
     // every tile is cut into `sp` rank-range shares (partial counters are summed in a global buffer).
     u32 n_tail = 0, sp = 1;
@@ -1592,6 +1597,7 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
         }
     }
     KSP_HIP(hipGetLastError());
+    }   // launch chunks
     KSP_HIP(hipEventRecord(e->ev[3], st));
     KSP_HIP(hipMemcpyAsync(e->h_count, a.out_count, 8, hipMemcpyDeviceToHost, st));
     KSP_HIP(hipStreamSynchronize(st));
@@ -1685,17 +1691,38 @@ int ksp_pairwise_host(const uint64_t* keys, const uint32_t* weights, const uint6
             }
         }
         if ((rc = ksp_engine_build_blocks(e, (const u64*)d_keys, (const u32*)d_w, offsets, n_sources, 0, nullptr))) break;
-        // batches of tile rows whose worst-case edge count fits the buffer
+        // Tile ranges as large as possible: start with everything; when the edge buffer overflows, grow it
+        // to the reported count if memory allows, otherwise halve the range (sparse inputs need one launch,
+        // dense ones are cut into ranges whose non-zero pairs fit).
         const u64 T = ksp_engine_num_tiles(e);
-        u64 cap = 1ull << 26;   // 64 Mi edges = 1 GiB
+        u64 cap = 1ull << 24;   // 16 Mi edges = 256 MiB to begin with
         if ((rc = ksp_device_malloc(device, cap * sizeof(ksp_edge), &d_edges))) break;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        const u64 max_cap = std::max<u64>(cap, (u64)(free_b / 2) / sizeof(ksp_edge));
         u64 t = 0;
-        u64 step = std::max<u64>(1, cap / ((u64)TB * TB));
+        u64 step = std::max<u64>(T, 1);
         ksp_stats acc{};
         while (t < T && !rc) {
             u64 t1 = std::min(T, t + step);
             u64 cnt = 0;
             rc = ksp_engine_join(e, t, t1, (ksp_edge*)d_edges, cap, &cnt, nullptr);
+            if (rc == KSP_E_OVERFLOW) {
+                rc = KSP_OK;
+                acc.ms_join += e->st.ms_join;
+                if (cnt <= max_cap) {
+                    (void)hipFree(d_edges);
+                    d_edges = nullptr;
+                    cap = std::min<u64>(max_cap, cnt + cnt / 16 + 1024);
+                    if ((rc = ksp_device_malloc(device, cap * sizeof(ksp_edge), &d_edges))) break;
+                } else if (t1 - t > 1) {
+                    step = (t1 - t) / 2;
+                } else {
+                    set_error("pairwise_host: a single tile yields more edges than fit in device memory");
+                    rc = KSP_E_LIMIT;
+                }
+                continue;
+            }
             if (rc) break;
             size_t old = all.size();
             all.resize(old + cnt);
