@@ -44,12 +44,28 @@ int run_pairwise(const std::string& prefix, int user_threads) {
     t0 = Clock::now();
     // dense source index = rank of the group ID, so that index order == ID order and the
     // engine's (i < j) is the reference's ascending(source_1, source_2) (:73-78, :218)
+    uint32_t max_id = 0;
+    for (auto& c : ix.colors)
+        for (uint32_t g : c.second) max_id = std::max(max_id, g);
     std::vector<uint32_t> ids;
-    for (auto& c : ix.colors) ids.insert(ids.end(), c.second.begin(), c.second.end());
-    std::sort(ids.begin(), ids.end());
-    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    std::vector<uint32_t> dense_of;          // direct table when the ID space is small enough
+    if (max_id < (1u << 28)) {
+        std::vector<uint8_t> seen((size_t)max_id + 1, 0);
+        for (auto& c : ix.colors)
+            for (uint32_t g : c.second) seen[g] = 1;
+        dense_of.assign((size_t)max_id + 1, 0);
+        for (uint32_t g = 0; g <= max_id; ++g)
+            if (seen[g]) { dense_of[g] = (uint32_t)ids.size(); ids.push_back(g); }
+        if (ix.colors.empty()) ids.clear();
+    } else {
+        for (auto& c : ix.colors) ids.insert(ids.end(), c.second.begin(), c.second.end());
+        std::sort(ids.begin(), ids.end());
+        ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    }
     const uint32_t N = (uint32_t)ids.size();
-    auto dense = [&](uint32_t g) { return (uint32_t)(std::lower_bound(ids.begin(), ids.end(), g) - ids.begin()); };
+    auto dense = [&](uint32_t g) -> uint32_t {
+        return dense_of.empty() ? (uint32_t)(std::lower_bound(ids.begin(), ids.end(), g) - ids.begin()) : dense_of[g];
+    };
 
     // colours in ascending id order -> every source's run of colour ids is sorted
     std::vector<uint32_t> order(ix.colors.size());
@@ -77,8 +93,9 @@ int run_pairwise(const std::string& prefix, int user_threads) {
             continue;
         }
         for (uint32_t g : c.second) {
-            offsets[dense(g) + 1]++;
-            wsum[dense(g)] += w;
+            const uint32_t di = dense(g);
+            offsets[di + 1]++;
+            wsum[di] += w;
         }
     }
     for (uint32_t s = 0; s < N; ++s) {
@@ -105,12 +122,15 @@ int run_pairwise(const std::string& prefix, int user_threads) {
     // duplicates of one source inside a colour cannot occur (flat_hash_set), but two colours
     // may narrow to the same uint32 id only via insert_or_assign, which load_index resolved.
 
+    const double t_transpose = since(t0);
     int device = 0;
     if (const char* d = std::getenv("KSPIDER_DEVICE")) device = std::atoi(d);
     ksp_edge* edges = nullptr;
     uint64_t n_edges = 0;
     ksp_stats st;
+    auto t1 = Clock::now();
     int rc = ksp_pairwise_host(keys.data(), wts.data(), offsets.data(), N, device, &edges, &n_edges, &st);
+    const double t_device = since(t1);
     if (rc != KSP_OK) return rc;
     std::vector<ksp::EdgeRow> rows;
     rows.reserve(n_edges + zero_pairs.size());
@@ -134,11 +154,13 @@ int run_pairwise(const std::string& prefix, int user_threads) {
         });
     }
     std::cout << "pairwise hashmap construction: " << since(t0) << " secs" << std::endl;
+    if (std::getenv("KSPIDER_VERBOSE"))
+        std::cout << "kspider_amd: host transposition " << t_transpose << " s, device round trip " << t_device
+                  << " s (stage 1 " << st.ms_build << " ms, join " << st.ms_join << " ms)" << std::endl;
     std::cout << "writing pairwise matrix to " << prefix << "_kSpider_pairwise.tsv" << std::endl;
     ksp::write_pairwise_tsv(prefix, rows, kmer_count, user_threads);
     if (std::getenv("KSPIDER_VERBOSE"))
-        std::cout << "kspider_amd: sources=" << N << " colour-entries=" << E << " pairs=" << rows.size()
-                  << " build_ms=" << st.ms_build << " join_ms=" << st.ms_join << std::endl;
+        std::cout << "kspider_amd: sources=" << N << " colour-entries=" << E << " pairs=" << rows.size() << std::endl;
     return KSP_OK;
 }
 

@@ -120,3 +120,35 @@ def test_zero_weight_colour_rows(oracle_lib, tmp_path):
     engine.pairwise(prefix, 1)
     assert open(prefix + "_kSpider_pairwise.tsv", "rb").read() == want_pw
     assert b"\t0\t0\t0\t0\n" in want_pw
+
+
+def test_uint32_narrowing_and_missing_kmer_counts(oracle_lib, tmp_path):
+    """The reference narrows colour ids and counts to uint32 with insert_or_assign (src/pairwise.cpp:103,
+    109,119) and divides by 0 when a group has no k-mer count (operator[] at :257-258): same rows, same text."""
+    import struct
+    prefix = str(tmp_path / "n")
+    # colours 5 and 5 + 2^32 collide after narrowing (the later one wins); group 9 has no k-mer count
+    co = np.array([0, 2, 4, 7], dtype=np.uint32)
+    src = np.array([1, 2, 3, 4, 1, 3, 9], dtype=np.uint32)
+    w = np.array([11, 22, 5], dtype=np.uint32)
+    oracle_lib.write_index(prefix, co, src, w, np.array([1, 2, 3, 4], dtype=np.uint32), np.array([100, 200, 300, 400]))
+    # rewrite the colour ids by hand: give the first two colours ids 5 and 5 + 2^32
+    path = prefix + "_color_to_sources.bin"
+    blob = bytearray(open(path, "rb").read())
+    n = struct.unpack_from("<Q", blob, 0)[0]
+    assert n == 3
+    pos, ids_at = 8, []
+    for _ in range(n):
+        ids_at.append(pos)
+        size, cap = struct.unpack_from("<QQ", blob, pos + 8)
+        pos += 8 + 16 + (cap + 17) + 4 * cap + 8
+    cur = [struct.unpack_from("<Q", blob, p)[0] for p in ids_at]
+    order = np.argsort(cur)                      # file order is scattered; pick two colours deterministically
+    struct.pack_into("<Q", blob, ids_at[order[0]], 5)
+    struct.pack_into("<Q", blob, ids_at[order[1]], 5 + (1 << 32))
+    open(path, "wb").write(bytes(blob))
+    want_pw, want_sk = _oracle_tsvs(oracle_lib, prefix, threads=1)
+    engine.pairwise(prefix, 1)
+    got = open(prefix + "_kSpider_pairwise.tsv", "rb").read()
+    assert got == want_pw
+    assert b"inf" in got                          # group 9: shared / 0
