@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """End-to-end drop-in comparison on index files: kSpider::pairwise() through libkspider_amd.so vs the CPU
-restatement of the reference (oracle), same index, byte-compared TSVs.   python tools/dropin_compare.py [N]"""
+restatement of the reference (oracle), same index, byte-compared TSVs.   python tests/dropin_compare.py [N]"""
 import os
 import subprocess
 import sys
