@@ -74,11 +74,11 @@ constexpr u32 INLINE_MAX = 4;         // sources whose 7-bit ids fit into the po
 // ------------------------------------------------------------------------------------
 
 // One workgroup per source: tag each entry with (block << 8 | local id) [and weight].
-// Weighted mode also records, per block, the largest per-source weight sum (the bound of
-// any pair counter that source takes part in).
+// Weighted mode also records the source's weight sum (the bound of any pair counter that source
+// takes part in; unweighted: k_src_size).
 template <bool W>
 __global__ void k_tag(const u64* __restrict__ off, const u32* __restrict__ wts, u32* __restrict__ val32,
-                      u64* __restrict__ val64, u32* __restrict__ blk_max) {
+                      u64* __restrict__ val64, u32* __restrict__ src_bound) {
     __shared__ unsigned long long acc;
     const u32 s = blockIdx.x;
     const u64 b = off[s], e = off[s + 1];
@@ -92,8 +92,57 @@ __global__ void k_tag(const u64* __restrict__ off, const u32* __restrict__ wts, 
     if (W) {
         if (part) atomicAdd(&acc, part);
         __syncthreads();
-        if (threadIdx.x == 0) atomicMax(&blk_max[s / TB], (u32)(acc > 0xFFFFFFFFull ? 0xFFFFFFFFull : acc));
+        if (threadIdx.x == 0) src_bound[s] = (u32)(acc > 0xFFFFFFFFull ? 0xFFFFFFFFull : acc);
     }
+}
+__global__ void k_src_size(const u64* __restrict__ off, u32* __restrict__ src_bound, u32 n_sources) {
+    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_sources) { const u64 c = off[s + 1] - off[s]; src_bound[s] = (u32)(c > 0xFFFFFFFFull ? 0xFFFFFFFFull : c); }
+}
+
+// ---- source reordering ---------------------------------------------------------------------
+// Sources that share keys are moved next to each other before they are cut into blocks: a source's
+// label is the smallest source id among the holders of any of its shared keys (one round of
+// min-label propagation over the key groups), and the sources are ordered by (label, id).  Related
+// sources then meet inside a block — their common keys collapse into one list word with a
+// multi-source posting — and most block pairs share no key at all, which the join skips.  The
+// engine works on the new indices; k_join maps them back when it emits an edge.
+__global__ void k_iota(u32* __restrict__ p, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+__global__ void k_rank_first(const u32* __restrict__ rk, u32* __restrict__ first, u64 n) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n && (e == 0 || rk[e] != rk[e - 1])) first[rk[e]] = (u32)e;
+}
+__device__ inline u32 src_of_tag(u32 t) { return (t >> 8) * TB + (t & 0xFFu); }
+template <class V>
+__global__ void k_label(const u32* __restrict__ rk, const V* __restrict__ vals, const u32* __restrict__ first,
+                        u32* __restrict__ label, u64 n) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const u32 s = src_of_tag((u32)vals[e]);
+    const u32 f = src_of_tag((u32)vals[first[rk[e]]]);   // entries of a key are in ascending source order
+    if (f < label[s]) atomicMin(&label[s], f);
+}
+// order[i] = i-th source in (label, id) order  ->  newidx[order[i]] = i; order itself is the inverse map
+__global__ void k_perm(const u32* __restrict__ order, u32* __restrict__ newidx, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) newidx[order[i]] = i;
+}
+template <class V>
+__global__ void k_retag(V* __restrict__ vals, const u32* __restrict__ newidx, u64 n) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const V v = vals[e];
+    const u32 ni = newidx[src_of_tag((u32)v)];
+    vals[e] = (V)((v & ~(V)0xFFFFFFFFu) | (V)(((ni / TB) << 8) | (ni % TB)));
+}
+// per block (of the new order): the largest per-source bound
+__global__ void k_blk_bound(const u32* __restrict__ src_bound, const u32* __restrict__ newidx, u32* __restrict__ blk_max,
+                            u32 n_sources) {
+    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_sources) atomicMax(&blk_max[newidx[s] / TB], src_bound[s]);
 }
 
 template <class V> __device__ inline u32 tag_of(V v) { return (u32)v; }
@@ -444,6 +493,7 @@ struct JoinArgs {
     const u32* cidx;    // nb * (ncell + 1): fine cell index, positions in the padded layout
     u32 ncell;          // fine cells per block (power of two, >= NP)
     const u32* blk_max; // nb: largest per-source k-mer count (weight sum) in the block
+    const u32* inv;     // engine source index -> caller's source id
     u32 nb;
     u32 n_sources;
     u64 tile_begin;
@@ -561,18 +611,55 @@ __device__ inline uint4 posting_mask(u32 inf, const uint4* __restrict__ bigmask)
     return make_uint4(m[0], m[1], m[2], m[3]);
 }
 
-// Large postings: the whole wave expands one match.  Lanes own the columns
-// (lane, lane + 64) of the tile, rows come from a scalar walk over the bits of mask A:
-// every LDS atomic touches 64 consecutive counters (conflict free).
+// Large postings: the whole wave expands one match, cA x cB counter updates.
 // SELF: both postings are the same key of the same block -> only pairs row < column.
+// Dense form (postings of up to DENSE_MAX sources on the column side): both member sets are
+// compacted into id lists in LDS and the lanes walk the cA x cB grid in 8 x 8 patches — every LDS
+// atomic carries up to 64 updates, however sparse the masks are.  Related sources sit in the same
+// block (source reordering), so postings of 5 .. 40 sources are the common case.
+// Row form (fuller masks): lanes own the columns (lane, lane + 64), rows come from a scalar walk
+// over the bits of mask A; every LDS atomic touches 64 consecutive counters (conflict free).
+constexpr u32 DENSE_MAX = 48;
+__device__ inline void mask_to_list(unsigned char* l, const u32 m0, const u32 m1, const u32 m2, const u32 m3, const int lane) {
+    const u32 below_lo = __builtin_amdgcn_mbcnt_hi(m1, __builtin_amdgcn_mbcnt_lo(m0, 0));   // members among columns < lane
+    const u32 below_hi = __builtin_amdgcn_mbcnt_hi(m3, __builtin_amdgcn_mbcnt_lo(m2, 0));   // ... among columns 64 .. 64 + lane - 1
+    const u32 wlo = lane < 32 ? m0 : m1, whi = lane < 32 ? m2 : m3;
+    if ((wlo >> (lane & 31)) & 1u) l[below_lo] = (unsigned char)lane;
+    if ((whi >> (lane & 31)) & 1u) l[(u32)__popc(m0) + (u32)__popc(m1) + below_hi] = (unsigned char)(lane + 64);
+}
 template <bool SELF, bool C16>
-__device__ inline void add_masks(u32* S, uint4 mA, uint4 mB, u32 w, int lane) {
-    const u32 bw0 = lane < 32 ? mB.x : mB.y, bw1 = lane < 32 ? mB.z : mB.w;
+__device__ inline void add_masks(u32* S, unsigned char* lst, uint4 mA, uint4 mB, u32 w, int lane) {
+    const u32 a0 = __builtin_amdgcn_readfirstlane(mA.x), a1 = __builtin_amdgcn_readfirstlane(mA.y);
+    const u32 a2 = __builtin_amdgcn_readfirstlane(mA.z), a3 = __builtin_amdgcn_readfirstlane(mA.w);
+    const u32 b0 = __builtin_amdgcn_readfirstlane(mB.x), b1 = __builtin_amdgcn_readfirstlane(mB.y);
+    const u32 b2 = __builtin_amdgcn_readfirstlane(mB.z), b3 = __builtin_amdgcn_readfirstlane(mB.w);
+    const u32 ca = (u32)(__popc(a0) + __popc(a1) + __popc(a2) + __popc(a3));
+    const u32 cb = SELF ? ca : (u32)(__popc(b0) + __popc(b1) + __popc(b2) + __popc(b3));
+    if (cb <= DENSE_MAX) {
+        unsigned char* la = lst;
+        unsigned char* lb = SELF ? lst : lst + TB;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        mask_to_list(la, a0, a1, a2, a3, lane);
+        if (!SELF) mask_to_list(lb, b0, b1, b2, b3, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const u32 li = (u32)lane >> 3, lj = (u32)lane & 7u;
+        for (u32 bi = 0; bi < ca; bi += 8) {
+            const u32 i = bi + li;
+            const u32 row = (u32)la[min(i, (u32)TB - 1u)] * TB;
+            for (u32 bj = SELF ? bi : 0u; bj < cb; bj += 8) {
+                const u32 j = bj + lj;
+                const u32 col = lb[min(j, (u32)TB - 1u)];
+                if (i < ca && j < cb && (!SELF || i < j)) s_add<C16>(S, row + col, w);   // (lists ascend: row < col in a self tile)
+            }
+        }
+        return;
+    }
+    const u32 bw0 = lane < 32 ? b0 : b1, bw1 = lane < 32 ? b2 : b3;
     const bool c0 = (bw0 >> (lane & 31)) & 1u, c1 = (bw1 >> (lane & 31)) & 1u;
-    const u32 words[4] = {mA.x, mA.y, mA.z, mA.w};
+    const u32 words[4] = {a0, a1, a2, a3};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        u32 word = __builtin_amdgcn_readfirstlane(words[k]);
+        u32 word = words[k];
         while (word) {
             const u32 r = 32u * k + (u32)__builtin_ctz(word);
             word &= word - 1;
@@ -595,7 +682,7 @@ struct Pending {
 // expands one match at a time from the 128-bit masks.
 // postings with 2..4 sources, or > 4 (masks): out of line, the hot path stays small
 template <bool C16>
-__device__ inline void pending_apply_complex(u32* S, const uint4* __restrict__ bigmask, const u32 qia,
+__device__ inline void pending_apply_complex(u32* S, unsigned char* lst, const uint4* __restrict__ bigmask, const u32 qia,
                                                    const u32 qib, const u32 qw, const bool cx, int lane) {
     const u32 both = qia | qib;
     const bool small = cx && both < BIG;
@@ -616,25 +703,26 @@ __device__ inline void pending_apply_complex(u32* S, const uint4* __restrict__ b
         const u32 ia = __builtin_amdgcn_readlane(qia, src);
         const u32 ib = __builtin_amdgcn_readlane(qib, src);
         const u32 w = __builtin_amdgcn_readlane(qw, src);
-        add_masks<false, C16>(S, posting_mask(ia, bigmask), posting_mask(ib, bigmask), w, lane);
+        add_masks<false, C16>(S, lst, posting_mask(ia, bigmask), posting_mask(ib, bigmask), w, lane);
     }
 }
 
 // Apply the pending matches of the wave to the tile.  Fast path (both keys held by a
 // single source of their block): one LDS atomic per lane, no loop.
 template <bool C16>
-__device__ inline void pending_apply(u32* S, const uint4* __restrict__ bigmask, const Pending& q, int lane) {
+__device__ inline void pending_apply(u32* S, unsigned char* lst, const uint4* __restrict__ bigmask, const Pending& q, int lane) {
     const u32 both = q.ia | q.ib;
     const bool simple = q.valid && both < 128u;
     if (simple) s_add<C16>(S, (q.ia << 7) | q.ib, q.w);
     const bool cx = q.valid && !simple;
-    if (__ballot(cx) != 0) pending_apply_complex<C16>(S, bigmask, q.ia, q.ib, q.w, cx, lane);
+    if (__ballot(cx) != 0) pending_apply_complex<C16>(S, lst, bigmask, q.ia, q.ib, q.w, cx, lane);
 }
 
 // Per-wave LDS state of the join.
 struct WaveLds {
     Window win;                 // B window as a 4-ary search tree
     unsigned short mq[WIN];     // match queue: (A slot << 8) | B slot
+    unsigned char lst[2 * TB];  // member lists of the two postings being expanded (add_masks)
 };
 
 // One step: every lane looks its 4 A keys (chunk base `ca`) up in the B window (base `cb`);
@@ -687,7 +775,7 @@ __device__ inline void match_step(const JoinArgs& a, u32* S, WaveLds& wl, const 
 #ifdef KSP_ABLATE
     if (!(a.dbg & 1))
 #endif
-    pending_apply<C16>(S, a.bigmask, pend, lane);
+    pending_apply<C16>(S, wl.lst, a.bigmask, pend, lane);
     pend.valid = false;
 #ifdef KSP_ABLATE
     if (a.dbg & 2) cnt = 0;
@@ -707,7 +795,7 @@ __device__ inline void match_step(const JoinArgs& a, u32* S, WaveLds& wl, const 
                 extra.ib = a.info[qb];
                 if (W) extra.w = a.bw[qa];
             }
-            pending_apply<C16>(S, a.bigmask, extra, lane);
+            pending_apply<C16>(S, wl.lst, a.bigmask, extra, lane);
         }
     }
     {
@@ -766,7 +854,7 @@ __device__ inline void join_windows(const JoinArgs& a, u32* S, WaveLds& wl, cons
                 B2 = load_b(a, cb + 2 * WIN, eb, lane);
             }
         }
-        pending_apply<C16>(S, a.bigmask, pend, lane);
+        pending_apply<C16>(S, wl.lst, a.bigmask, pend, lane);
     }
 }
 
@@ -859,8 +947,8 @@ __device__ inline void join_cells(const JoinArgs& a, u32* S, WaveLds& wl, const 
         cell_process<W, C16>(a, S, wl, L1, s0, s1, s2, pend1, lane);
         cell_fetch(a, cI, cJ, c + 3, cend, m, lane, L1);
     }
-    pending_apply<C16>(S, a.bigmask, pend0, lane);
-    pending_apply<C16>(S, a.bigmask, pend1, lane);
+    pending_apply<C16>(S, wl.lst, a.bigmask, pend0, lane);
+    pending_apply<C16>(S, wl.lst, a.bigmask, pend1, lane);
 }
 
 // Compact the non-zero counters of one tile into (source_1, source_2, shared) records:
@@ -880,9 +968,11 @@ __device__ inline void emit_tile(const JoinArgs& a, const u32 I, const u32 J, co
         if (nz) {
             const u64 pos = wbase + __popcll(mask & ((1ull << lane) - 1ull));
             if (pos < a.cap) {
+                // back from the engine's source order to the caller's ids
+                const u32 o1 = a.inv[gi0 + (u32)(idx / TB)], o2 = a.inv[gj0 + (u32)(idx % TB)];
                 ksp_edge e;
-                e.source_1 = gi0 + (u32)(idx / TB);
-                e.source_2 = gj0 + (u32)(idx % TB);
+                e.source_1 = min(o1, o2);
+                e.source_2 = max(o1, o2);
                 e.shared = v;
                 a.out[pos] = e;
             }
@@ -921,7 +1011,8 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
 
     if (I == J) {
         // self tile: every key of the block matches itself; only keys held by >= 2 sources
-        // produce pairs (i < j because posting ids are ascending).
+        // produce pairs (counted in the upper triangle: posting ids follow the caller's source order,
+        // not the engine's)
         const u32 kb = a.blk_pos[I], ke = kb + (a.blk_raw[I + 1] - a.blk_raw[I]);
         for (u32 k0 = kb; k0 < ke; k0 += JW * 64) {   // uniform trip count: the big path is wave-wide
             const u32 k = k0 + tid;
@@ -932,8 +1023,11 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
             if (!big) {
                 const u32 n = (inf >> 29) + 1;
                 for (u32 x = 0; x + 1 < n; ++x) {
-                    const u32 row = ((inf >> (7 * x)) & 127u) * TB;
-                    for (u32 y = x + 1; y < n; ++y) s_add<C16>(S, row + ((inf >> (7 * y)) & 127u), w);
+                    const u32 ix = (inf >> (7 * x)) & 127u;
+                    for (u32 y = x + 1; y < n; ++y) {
+                        const u32 iy = (inf >> (7 * y)) & 127u;
+                        s_add<C16>(S, min(ix, iy) * TB + max(ix, iy), w);
+                    }
                 }
             }
             unsigned long long todo = __ballot(big);
@@ -943,7 +1037,7 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
                 const u32 si = __builtin_amdgcn_readlane(inf, src);
                 const u32 sw = __builtin_amdgcn_readlane(w, src);
                 const uint4 m = posting_mask(si, a.bigmask);
-                add_masks<true, C16>(S, m, m, sw, lane);
+                add_masks<true, C16>(S, wlds[wv].lst, m, m, sw, lane);
             }
         }
     } else if (CELLS) {
@@ -1012,13 +1106,14 @@ struct ksp_engine {
     u32 ncell = ksp::NP;          // fine rank cells per block (power of two)
     bool use_cells = true;        // rank-aligned cell join (KSP_JOIN=window selects the sliding-window merge)
     bool full_sort = false;       // keys defeat the 32-bit prefix sort: use all bits
+    bool reorder = true;          // order the sources by shared-key label before cutting blocks (KSP_REORDER=0: off)
     bool need32 = false;          // some tile pairs two blocks that both hold a source with >= 2^16 k-mers
     int key_bits = 64;
     std::vector<u64> h_off;
     std::vector<u32> h_blk_off;   // distinct-key offsets of the block lists (host copy)
     std::vector<u32> h_blk_max;   // per block: largest per-source k-mer count / weight sum
     // workspace
-    ksp::Buf d_off, KA, KB, VA, VB, R1, FK, FT, asm_small, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, blk_max, part, scalars, count, tailbuf;
+    ksp::Buf d_off, KA, KB, VA, VB, R1, FK, FT, asm_small, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, blk_max, part, scalars, count, tailbuf, smap;
     u32 slots = 0;                // workgroups of k_join the chip holds at once (occupancy x CUs)
     unsigned long long* h_count = nullptr;   // pinned
     u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
@@ -1079,10 +1174,22 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     int bbits = 1;
     while ((1u << bbits) < nb) ++bbits;
 
-    if (W) KSP_HIP(hipMemsetAsync(e->blk_max.p, 0, ((size_t)nb + 1) * 4, st));
+    // per-source maps: [0] label, [1] iota, [2] sorted labels, [3] order (= engine index -> source id),
+    // [4] newidx (source id -> engine index), [5] bound of a source's pair counters
+    const size_t NN = ((size_t)N + 64) & ~(size_t)63;
+    if ((rc = e->smap.ensure(6 * NN * 4))) return rc;
+    u32* sm = e->smap.as<u32>();
+    u32 *label = sm, *iota = sm + NN, *labs = sm + 2 * NN, *order = sm + 3 * NN, *newidx = sm + 4 * NN, *sbound = sm + 5 * NN;
     if (W || e->nparts == 1)   // (weighted slices still need the per-source weight sums of all entries)
         hipLaunchKernelGGL((k_tag<W>), dim3(N), dim3(256), 0, st, d_off, d_w, W ? nullptr : (u32*)VA,
-                           W ? (u64*)VA : nullptr, e->blk_max.as<u32>());
+                           W ? (u64*)VA : nullptr, sbound);
+    if (!W) hipLaunchKernelGGL(k_src_size, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_off, sbound, N);
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, iota, N);
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, N);    // identity until the labels are known
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, newidx, N);
+    const bool reorder = e->reorder && e->nparts == 1;
+    KSP_HIP(hipMemsetAsync(e->blk_max.p, 0, ((size_t)nb + 1) * 4, st));
+    if (!reorder) hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
     // slice mode (multi-GPU build): keep only the entries of this part's key range — one contiguous
     // sub-run per (sorted) source, so the cost is proportional to the slice, not to the sketch set
     const u64* keys_in = d_keys;
@@ -1159,6 +1266,22 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     const u64 m = e->h_scal[6];
     e->n_kept = m;
     if (m == 0) return KSP_OK;             // no key is shared by two sources: no pair at all
+    if (reorder) {
+        // order the sources by (label, id): label = smallest source id among the holders of its shared keys
+        u32* first = (u32*)e->KB.p;        // U entries (the packed prefix sums are dead)
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, label, N);
+        hipLaunchKernelGGL(k_rank_first, dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, first, m);
+        hipLaunchKernelGGL((k_label<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, VA, first, label, m);
+        int lbits = 1;
+        while (lbits < 32 && (N >> lbits)) ++lbits;
+        tb = 0;
+        KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, label, labs, iota, order, (size_t)N, 0, lbits, st));
+        if ((rc = e->tmp.ensure(tb))) return rc;
+        KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, label, labs, iota, order, (size_t)N, 0, lbits, st));
+        hipLaunchKernelGGL(k_perm, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, newidx, N);
+        hipLaunchKernelGGL((k_retag<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, VA, newidx, m);
+        hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
+    }
     // sort 2: stable by block id (bits [8, 8+bbits) of the tag), payload = rank:  VA,rank1 -> VB,rk2
     u32* rk2 = (u32*)KA;                   // KA (sorted keys) is dead from here on
     tb = 0;
@@ -1237,7 +1360,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
-                        &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf};
+                        &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
@@ -1248,8 +1371,7 @@ void ksp_engine_destroy(ksp_engine* e) {
 // host-side bookkeeping once the full block lists sit in the engine's arrays
 static int finish_build(ksp_engine* e) {
     e->st.key_bits = e->key_bits;
-    if (e->weighted)
-        KSP_HIP(hipMemcpy(e->h_blk_max.data(), e->blk_max.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
+    KSP_HIP(hipMemcpy(e->h_blk_max.data(), e->blk_max.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
     {
         u32 big_blocks = 0;
         for (u32 b = 0; b < e->nb; ++b) big_blocks += e->h_blk_max[b] >= 65536u;
@@ -1315,14 +1437,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
         e->use_cells = !(jm && std::string(jm) == "window");
     }
     if ((rc = e->blk_max.ensure(((size_t)e->nb + 2) * 4))) return rc;
-    if (!e->weighted) {   // raw hashes: a source's bound is its k-mer count
-        for (u32 s = 0; s < n_sources; ++s) {
-            u64 c = h_offsets[s + 1] - h_offsets[s];
-            u32& m = e->h_blk_max[s / TB];
-            m = std::max<u32>(m, (u32)std::min<u64>(c, 0xFFFFFFFFull));
-        }
-        KSP_HIP(hipMemcpyAsync(e->blk_max.p, e->h_blk_max.data(), ((size_t)e->nb + 1) * 4, hipMemcpyHostToDevice, st));
-    }
+    if (const char* ro = std::getenv("KSP_REORDER")) e->reorder = std::atoi(ro) != 0;   // diagnostic / tests
     for (int attempt = 0; attempt < 2; ++attempt) {
         rc = e->weighted ? build_impl<true>(e, d_keys, d_weights, st) : build_impl<false>(e, d_keys, d_weights, st);
         if (rc) return rc;
@@ -1539,6 +1654,7 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     KSP_HIP(hipEventRecord(e->ev[2], st));
     dim3 block(JW * 64);
     a.blk_max = e->blk_max.as<u32>();
+    a.inv = e->smap.as<u32>() + 3 * (((size_t)e->n_sources + 64) & ~(size_t)63);
     // HIP caps a launch at 2^32 threads: at most 4 Mi workgroups of 512 threads per launch (a larger grid
     // silently runs only part of its blocks — seen with 30.5 M tiles on MI355X / ROCm 7.2)
     const u64 kMaxTilesPerLaunch = 4ull << 20;
