@@ -50,6 +50,9 @@ typedef struct ksp_stats {
     float ms_join;          /* HIP-event time of the last join kernel launch        */
     int weighted;
     int key_bits;
+    uint64_t n_active_tiles;    /* tiles with something to count (block pairs sharing a key, diagonal
+                                   tiles of blocks with a multi-source key); = n_tiles in dense mode */
+    uint64_t last_active_tiles; /* ... among the tiles of the last ksp_engine_join                   */
 } ksp_stats;
 
 const char* ksp_last_error(void);
@@ -75,6 +78,9 @@ int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_
 uint64_t ksp_engine_num_tiles(const ksp_engine* e);
 /* Source pairs covered by tiles [tile_begin, tile_end): the worst-case edge count.     */
 uint64_t ksp_engine_tile_pairs(const ksp_engine* e, uint64_t tile_begin, uint64_t tile_end);
+/* Tighter bound on the edges tiles [tile_begin, tile_end) can produce: the source pairs of the tiles
+ * that share a key at all (stage 1 knows them; equals ksp_engine_tile_pairs in dense mode).       */
+uint64_t ksp_engine_edge_bound(const ksp_engine* e, uint64_t tile_begin, uint64_t tile_end);
 
 /* Stage 2: join tiles [tile_begin, tile_end) and append every pair with shared > 0 to
  * d_edges (device buffer of `capacity` edges; order unspecified).  *h_count receives the

@@ -392,6 +392,49 @@ __global__ void k_cidx(const u32* __restrict__ brk, const u32* __restrict__ blk_
     cidx[i] = lo;
 }
 
+__device__ inline u64 tile_row_start_dev(u64 r, u64 nb) { return r * nb - r * (r - 1) / 2; }
+
+// ---- which block pairs share a key, and how much work a diagonal tile is ------------------------
+// (rank, block) of every list word; sorted by rank, the words of one key are adjacent and the
+// block pairs among them are exactly the tiles that have something to count.
+__global__ void k_list_pairs(const u32* __restrict__ brk, const u32* __restrict__ info, const uint4* __restrict__ bigmask,
+                             const u32* __restrict__ blk_raw, const u32* __restrict__ blk_pos, u32* __restrict__ pr,
+                             u32* __restrict__ pb, unsigned long long* __restrict__ work) {
+    // grid (block, share): also sums the pair updates of the block's diagonal tile, C(holders, 2) per key
+    const u32 b = blockIdx.x;
+    const u32 cnt = blk_raw[b + 1] - blk_raw[b], src = blk_pos[b], dst = blk_raw[b];
+    const u32 i0 = (u32)(((u64)cnt * blockIdx.y) / gridDim.y), i1 = (u32)(((u64)cnt * (blockIdx.y + 1)) / gridDim.y);
+    unsigned long long acc = 0;
+    for (u32 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        pr[dst + i] = brk[src + i];
+        pb[dst + i] = b;
+        const u32 inf = info[src + i];
+        u32 c;
+        if (inf >= BIG) { const uint4 m = bigmask[inf & ~BIG]; c = __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w); }
+        else c = (inf >> 29) + 1;
+        acc += (unsigned long long)c * (c - 1) / 2;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&work[b], acc);
+}
+// one byte per tile: plain idempotent stores (a few hundred active tiles take millions of hits —
+// atomics on the same words would serialise in L2)
+__global__ void k_tile_flags(const u32* __restrict__ pr, const u32* __restrict__ pb, u64 n, u32 nb,
+                             unsigned char* __restrict__ flags) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 r = pr[i], I = pb[i];
+    for (u64 j = i + 1; j < n && pr[j] == r; ++j) {   // (stable sort: blocks ascend inside a key)
+        const u64 t = tile_row_start_dev(I, nb) + (pb[j] - I);
+        if (!flags[t]) flags[t] = 1;
+    }
+}
+__global__ void k_pack_flags(const unsigned char* __restrict__ flags, u64 n, u32* __restrict__ bits) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;   // blockDim is a multiple of 64
+    const unsigned long long m = __ballot(t < n && flags[t] != 0);
+    if ((threadIdx.x & 63) == 0) { bits[t >> 5] = (u32)m; bits[(t >> 5) + 1] = (u32)(m >> 32); }
+}
+
 // ---- key-range slices (multi-GPU build) -----------------------------------------------
 // Rank p of G builds the block lists of the keys in its 1/G share of the hash range only
 // (filter -> same pipeline on n/G entries); the slices are exchanged (all-gather) and every
@@ -494,6 +537,12 @@ struct JoinArgs {
     u32 ncell;          // fine cells per block (power of two, >= NP)
     const u32* blk_max; // nb: largest per-source k-mer count (weight sum) in the block
     const u32* inv;     // engine source index -> caller's source id
+    // work-list mode (sched != NULL): only the block pairs that share a key are visited, and a
+    // tile is cut into as many shares (rank ranges / key ranges) as its estimated work asks for
+    const u32* sched;   // per workgroup of the whole work list: index of its active tile
+    const u32* act;     // per active tile: I, J, first workgroup, index among the split tiles (4 x u32)
+    u32 wg0;            // first workgroup of this launch in the work list
+    u32 split0;         // index of the first split tile of this join call (tail buffer slot 0)
     u32 nb;
     u32 n_sources;
     u64 tile_begin;
@@ -696,14 +745,21 @@ __device__ inline void pending_apply_complex(u32* S, unsigned char* lst, const u
             if (act) s_add<C16>(S, row | ((qib >> (7 * y)) & 127u), qw);
         }
     }
-    unsigned long long todo = __ballot(cx && !small);
+    const bool large = cx && !small;
+    unsigned long long todo = __ballot(large);
+    if (todo == 0) return;
+    // every lane fetches the masks of its own match first: one round of memory latency for the
+    // whole wave instead of one per match inside the serial loop below
+    uint4 mA = make_uint4(0, 0, 0, 0), mB = mA;
+    if (large) { mA = posting_mask(qia, bigmask); mB = posting_mask(qib, bigmask); }
     while (todo) {   // wave-cooperative expansion, one match at a time
         const int src = __builtin_ctzll(todo);
         todo &= todo - 1;
-        const u32 ia = __builtin_amdgcn_readlane(qia, src);
-        const u32 ib = __builtin_amdgcn_readlane(qib, src);
-        const u32 w = __builtin_amdgcn_readlane(qw, src);
-        add_masks<false, C16>(S, lst, posting_mask(ia, bigmask), posting_mask(ib, bigmask), w, lane);
+        const uint4 a = make_uint4(__builtin_amdgcn_readlane(mA.x, src), __builtin_amdgcn_readlane(mA.y, src),
+                                   __builtin_amdgcn_readlane(mA.z, src), __builtin_amdgcn_readlane(mA.w, src));
+        const uint4 b = make_uint4(__builtin_amdgcn_readlane(mB.x, src), __builtin_amdgcn_readlane(mB.y, src),
+                                   __builtin_amdgcn_readlane(mB.z, src), __builtin_amdgcn_readlane(mB.w, src));
+        add_masks<false, C16>(S, lst, a, b, __builtin_amdgcn_readlane(qw, src), lane);
     }
 }
 
@@ -992,19 +1048,29 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
     // Tail splitting: the tiles of the last, partially filled round of workgroup slots are cut
     // into tail_sp rank-range shares each, so that the round takes 1/tail_sp of a tile time.
     u32 sub = 0, sp = 1, tail_id = 0xFFFFFFFFu;
-    u64 tile = a.tile_begin + blockIdx.x;
-    if (blockIdx.x >= a.n_normal) {
-        const u32 r = blockIdx.x - a.n_normal;
-        tail_id = r / a.tail_sp;
-        sub = r % a.tail_sp;
-        sp = a.tail_sp;
-        tile = a.tile_begin + a.n_normal + tail_id;
-    }
     u32 I, J;
-    tile_decode(tile, a.nb, I, J);
+    if (a.sched) {
+        const u32 wg = a.wg0 + blockIdx.x;
+        const u32* t = a.act + 4 * (size_t)a.sched[wg];
+        I = t[0]; J = t[1];
+        sub = wg - t[2];
+        sp = t[6] - t[2];                       // (next tile's first workgroup)
+        if (sp > 1) tail_id = t[3] - a.split0;
+    } else {
+        u64 tile = a.tile_begin + blockIdx.x;
+        if (blockIdx.x >= a.n_normal) {
+            const u32 r = blockIdx.x - a.n_normal;
+            tail_id = r / a.tail_sp;
+            sub = r % a.tail_sp;
+            sp = a.tail_sp;
+            tile = a.tile_begin + a.n_normal + tail_id;
+        }
+        tile_decode(tile, a.nb, I, J);
+        if (I == J && sub != 0) return;   // (dense mode) a diagonal tail tile is done by its first share alone
+        if (I == J) sp = 1;
+    }
     // 16-bit counters are exact iff one of the two blocks has no source with >= 2^16 k-mers
     if ((min(a.blk_max[I], a.blk_max[J]) < 65536u) != C16) return;
-    if (I == J && sub != 0) return;   // a diagonal tail tile is done by its first share alone
 
     for (int i = tid; i < (C16 ? TB * TB / 2 : TB * TB); i += JW * 64) S[i] = 0;
     __syncthreads();
@@ -1013,7 +1079,8 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
         // self tile: every key of the block matches itself; only keys held by >= 2 sources
         // produce pairs (counted in the upper triangle: posting ids follow the caller's source order,
         // not the engine's)
-        const u32 kb = a.blk_pos[I], ke = kb + (a.blk_raw[I + 1] - a.blk_raw[I]);
+        const u32 kb0 = a.blk_pos[I], klen = a.blk_raw[I + 1] - a.blk_raw[I];
+        const u32 kb = kb0 + (u32)(((u64)klen * sub) / sp), ke = kb0 + (u32)(((u64)klen * (sub + 1)) / sp);   // this share's keys
         for (u32 k0 = kb; k0 < ke; k0 += JW * 64) {   // uniform trip count: the big path is wave-wide
             const u32 k = k0 + tid;
             u32 inf = 0;
@@ -1031,12 +1098,14 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
                 }
             }
             unsigned long long todo = __ballot(big);
+            uint4 mk = make_uint4(0, 0, 0, 0);
+            if (big) mk = a.bigmask[inf & ~BIG];   // all masks of the wave in one round of memory latency
             while (todo) {
                 const int src = __builtin_ctzll(todo);
                 todo &= todo - 1;
-                const u32 si = __builtin_amdgcn_readlane(inf, src);
                 const u32 sw = __builtin_amdgcn_readlane(w, src);
-                const uint4 m = posting_mask(si, a.bigmask);
+                const uint4 m = make_uint4(__builtin_amdgcn_readlane(mk.x, src), __builtin_amdgcn_readlane(mk.y, src),
+                                           __builtin_amdgcn_readlane(mk.z, src), __builtin_amdgcn_readlane(mk.w, src));
                 add_masks<true, C16>(S, wlds[wv].lst, m, m, sw, lane);
             }
         }
@@ -1065,7 +1134,12 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
 __global__ __launch_bounds__(JW * 64) void k_tail_emit(JoinArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     u32 I, J;
-    tile_decode(a.tile_begin + a.n_normal + blockIdx.x, a.nb, I, J);
+    if (a.sched) {   // work-list mode: a.sched = the split tiles of the work list (indices into a.act)
+        const u32* t = a.act + 4 * (size_t)a.sched[a.split0 + blockIdx.x];
+        I = t[0]; J = t[1];
+    } else {
+        tile_decode(a.tile_begin + a.n_normal + blockIdx.x, a.nb, I, J);
+    }
     const u32* src = a.tailbuf + (size_t)blockIdx.x * (TB * TB);
     emit_tile(a, I, J, tid, lane, [&](int idx) { return src[idx]; });
 }
@@ -1115,8 +1189,16 @@ struct ksp_engine {
     // workspace
     ksp::Buf d_off, KA, KB, VA, VB, R1, FK, FT, asm_small, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, blk_max, part, scalars, count, tailbuf, smap;
     u32 slots = 0;                // workgroups of k_join the chip holds at once (occupancy x CUs)
+    // work list of the join (built by finish_build; empty -> dense mode: every tile is visited)
+    bool sched_on = false;
+    bool have_bits = false;       // tbits / dwork hold this build's tile bitmap and diagonal work
+    std::vector<u64> act_tid;     // active tiles (row-major tile ids, ascending)
+    std::vector<u32> act_rec;     // per active tile: I, J, first workgroup, split index (+ one sentinel record)
+    std::vector<u32> split_list;  // active-tile indices of the tiles cut into several shares
+    ksp::Buf tbits, dwork, d_act, d_wg, d_split;
     unsigned long long* h_count = nullptr;   // pinned
     u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
+    u64 h_scal_words = 0, h_scal_keys = 0;   // list words / distinct shared keys of the lists being finished
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     ksp_stats st{};
 };
@@ -1321,6 +1403,45 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     return KSP_OK;
 }
 
+// Last step of stage 1 (single build and assemble alike): the bitmap of block pairs that share a
+// key and the pair-update count of every diagonal tile; finish_build turns them into the work list.
+static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
+    e->have_bits = false;
+    const u32 nb = e->nb;
+    const u64 K = e->h_scal_words;   // list words (set by the caller)
+    const u64 U = e->h_scal_keys;
+    const u64 T = (u64)nb * (nb + 1) / 2;
+    if (std::getenv("KSP_NO_SCHED") || K == 0 || U == 0) return KSP_OK;
+    // a key in many blocks means most block pairs are active anyway (and the pair walk below is
+    // quadratic in the blocks per key): leave such inputs to the dense mode
+    if (K > 6 * U || T > (1ull << 26)) return KSP_OK;
+    int rc;
+    const size_t bit_words = (size_t)(((T + 63) / 64) * 2 + 2);
+    if ((rc = e->tbits.ensure(bit_words * 4 + T + 64))) return rc;   // packed bitmap, then one flag byte per tile
+    if ((rc = e->dwork.ensure(((size_t)nb + 1) * 8))) return rc;
+    if ((rc = e->KA.ensure((K + 4) * 8))) return rc;
+    if ((rc = e->KB.ensure((K + 4) * 8))) return rc;
+    u32 *pr = (u32*)e->KA.p, *pb = pr + (K + 4), *pr2 = (u32*)e->KB.p, *pb2 = pr2 + (K + 4);
+    unsigned char* flags = (unsigned char*)e->tbits.p + bit_words * 4;
+    KSP_HIP(hipMemsetAsync(e->tbits.p, 0, bit_words * 4 + T + 64, st));
+    KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 1) * 8, st));
+    const u32 shares = (u32)std::min<u64>(64, std::max<u64>(1, 2048 / nb));
+    hipLaunchKernelGGL(k_list_pairs, dim3(nb, shares), dim3(256), 0, st, e->bkeys.as<u32>(), e->info.as<u32>(),
+                       e->mm.as<uint4>(), e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), pr, pb,
+                       e->dwork.as<unsigned long long>());
+    int rbits = 1;
+    while (rbits < 32 && (U >> rbits)) ++rbits;
+    size_t tb = 0;
+    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, pr, pr2, pb, pb2, (size_t)K, 0, rbits, st));
+    if ((rc = e->tmp.ensure(tb))) return rc;
+    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, pr, pr2, pb, pb2, (size_t)K, 0, rbits, st));
+    hipLaunchKernelGGL(k_tile_flags, dim3(grid_for(K, 256)), dim3(256), 0, st, pr2, pb2, K, nb, flags);
+    hipLaunchKernelGGL(k_pack_flags, dim3(grid_for(T, 256)), dim3(256), 0, st, flags, T, e->tbits.as<u32>());
+    KSP_HIP(hipGetLastError());
+    e->have_bits = true;
+    return KSP_OK;
+}
+
 }  // namespace ksp
 
 using namespace ksp;
@@ -1360,12 +1481,97 @@ void ksp_engine_destroy(ksp_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
-                        &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap};
+                        &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
+                        &e->d_wg, &e->d_split};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
     for (int i = 0; i < 4; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     delete e;
+}
+
+static int query_slots(ksp_engine* e) {
+    if (e->slots) return KSP_OK;
+    int per_cu = 0, cus = 0;
+    KSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_join<false, true, true>, JW * 64, 0));
+    KSP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+    e->slots = (u32)std::max(1, per_cu * cus);
+    return KSP_OK;
+}
+
+// The join's work list: the tiles that have something to count (block pairs sharing a key, and the
+// diagonal tiles of blocks with a multi-source key), each cut into shares by estimated work so that
+// a few heavy tiles (related sources end up in the same block: the diagonal ones) do not serialise
+// the launch.  Costs are in rough LDS-pipe cycles: ~8 per list word streamed and searched, ~1/2 per
+// pair update of a diagonal tile, ~2000 per workgroup (zeroing and flushing the counter tile).
+static int build_schedule(ksp_engine* e) {
+    e->sched_on = false;
+    e->act_tid.clear(); e->act_rec.clear(); e->split_list.clear();
+    e->st.n_active_tiles = e->st.n_tiles;
+    if (!e->have_bits) return KSP_OK;
+    const u32 nb = e->nb;
+    const u64 T = (u64)nb * (nb + 1) / 2;
+    const size_t words = (size_t)(((T + 63) / 64) * 2);
+    std::vector<u32> bits(words + 2);
+    std::vector<unsigned long long> dw((size_t)nb + 1);
+    KSP_HIP(hipMemcpy(bits.data(), e->tbits.p, words * 4, hipMemcpyDeviceToHost));
+    KSP_HIP(hipMemcpy(dw.data(), e->dwork.p, ((size_t)nb + 1) * 8, hipMemcpyDeviceToHost));
+    u64 active = 0;
+    for (size_t i = 0; i < words; ++i) active += (u64)__builtin_popcount(bits[i]);
+    for (u32 b = 0; b < nb; ++b) active += dw[b] != 0;
+    if (active * 2 > T) return KSP_OK;   // mostly dense: the plain tile walk is as good
+    int rc;
+    if ((rc = query_slots(e))) return rc;
+    auto words_of = [&](u32 b) { return (u64)(e->h_blk_off[b + 1] - e->h_blk_off[b]); };
+    auto cost_of = [&](u32 I, u32 J) -> u64 {
+        return I == J ? dw[I] / 2 + 10 * words_of(I) + 2000 : 8 * (words_of(I) + words_of(J)) + 2000;
+    };
+    // pass 1: active tiles and total cost
+    u64 total = 0;
+    e->act_tid.reserve((size_t)active);
+    for (u32 I = 0; I < nb; ++I) {
+        const u64 row = tile_row_start(I, nb);
+        if (dw[I]) { e->act_tid.push_back(row); total += cost_of(I, I); }
+        for (u64 t = row + 1; t < row + (nb - I);) {
+            const u32 wrd = bits[t >> 5] >> (t & 31);
+            if (!wrd) { t = (t | 31) + 1; continue; }
+            const u64 tt = t + (u64)__builtin_ctz(wrd);
+            if (tt >= row + (nb - I)) break;
+            e->act_tid.push_back(tt);
+            total += cost_of(I, I + (u32)(tt - row));
+            t = tt + 1;
+        }
+    }
+    const size_t A = e->act_tid.size();
+    const u64 target = std::max<u64>(total / ((u64)e->slots * 3) + 1, 20000);
+    // pass 2: shares
+    std::vector<u32> wg;
+    wg.reserve(A + (size_t)e->slots * 4);
+    e->act_rec.resize(4 * (A + 1));
+    u32 nsplit = 0;
+    for (size_t i = 0; i < A; ++i) {
+        u32 I, J;
+        tile_decode(e->act_tid[i], nb, I, J);
+        u64 sp = (cost_of(I, J) + target - 1) / target;
+        sp = std::min<u64>(std::max<u64>(sp, 1), 32);
+        u32* r = &e->act_rec[4 * i];
+        r[0] = I; r[1] = J; r[2] = (u32)wg.size(); r[3] = nsplit;
+        if (sp > 1) { e->split_list.push_back((u32)i); ++nsplit; }
+        for (u64 q = 0; q < sp; ++q) wg.push_back((u32)i);
+        if (wg.size() > 0x7FFFFFF0ull) return KSP_OK;   // (absurdly many shares: stay dense)
+    }
+    u32* r = &e->act_rec[4 * A];
+    r[0] = 0; r[1] = 0; r[2] = (u32)wg.size(); r[3] = nsplit;
+    if ((rc = e->d_act.ensure(e->act_rec.size() * 4))) return rc;
+    if ((rc = e->d_wg.ensure(std::max<size_t>(1, wg.size()) * 4))) return rc;
+    if ((rc = e->d_split.ensure(std::max<size_t>(1, e->split_list.size()) * 4))) return rc;
+    KSP_HIP(hipMemcpy(e->d_act.p, e->act_rec.data(), e->act_rec.size() * 4, hipMemcpyHostToDevice));
+    if (!wg.empty()) KSP_HIP(hipMemcpy(e->d_wg.p, wg.data(), wg.size() * 4, hipMemcpyHostToDevice));
+    if (!e->split_list.empty())
+        KSP_HIP(hipMemcpy(e->d_split.p, e->split_list.data(), e->split_list.size() * 4, hipMemcpyHostToDevice));
+    e->sched_on = true;
+    e->st.n_active_tiles = A;
+    return KSP_OK;
 }
 
 // host-side bookkeeping once the full block lists sit in the engine's arrays
@@ -1380,6 +1586,8 @@ static int finish_build(ksp_engine* e) {
     e->h_blk_off.resize((size_t)e->nb + 1);
     KSP_HIP(hipMemcpy(e->h_blk_off.data(), e->blk_raw.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
     e->st.n_block_keys = e->h_blk_off[e->nb];
+    int rc = build_schedule(e);
+    if (rc) return rc;
     e->built = true;
     return KSP_OK;
 }
@@ -1441,7 +1649,6 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     for (int attempt = 0; attempt < 2; ++attempt) {
         rc = e->weighted ? build_impl<true>(e, d_keys, d_weights, st) : build_impl<false>(e, d_keys, d_weights, st);
         if (rc) return rc;
-        KSP_HIP(hipEventRecord(e->ev[1], st));
         KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 64, hipMemcpyDeviceToHost, st));
         KSP_HIP(hipStreamSynchronize(st));
         if ((u32)e->h_scal[4] == 0) break;
@@ -1449,6 +1656,14 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
         // redo with a full-width sort and remember it for later builds on this engine
         e->full_sort = true;
     }
+    e->have_bits = false;
+    if (nparts == 1 && e->n_kept) {   // the work list of the join (slices: after the assemble)
+        e->h_scal_words = e->h_scal[1];
+        e->h_scal_keys = e->h_scal[2];
+        if ((rc = launch_sched_kernels(e, st))) return rc;
+    }
+    KSP_HIP(hipEventRecord(e->ev[1], st));
+    KSP_HIP(hipStreamSynchronize(st));
     KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
     e->st.key_bits = e->key_bits;
     return KSP_OK;
@@ -1585,6 +1800,9 @@ int ksp_engine_assemble(ksp_engine* e, uint32_t nparts, const uint64_t* h_sizes 
     hipLaunchKernelGGL(k_cidx, dim3(grid_for((u64)nb * (e->ncell + 1), 256)), dim3(256), 0, st, e->bkeys.as<u32>(),
                        e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), scal, e->part.as<u32>(), nb, e->ncell);
     KSP_HIP(hipGetLastError());
+    e->h_scal_words = ktot;
+    e->h_scal_keys = utot;
+    if ((rc = launch_sched_kernels(e, st))) return rc;
     KSP_HIP(hipEventRecord(e->ev[1], st));
     KSP_HIP(hipStreamSynchronize(st));
     float ms = 0;
@@ -1615,6 +1833,21 @@ uint64_t ksp_engine_tile_pairs(const ksp_engine* e, uint64_t t0, uint64_t t1) {
             pairs += (JJ == I) ? nI * (nI - 1) / 2 : nI * nJ;
         }
         t = stop;
+    }
+    return pairs;
+}
+
+uint64_t ksp_engine_edge_bound(const ksp_engine* e, uint64_t t0, uint64_t t1) {
+    if (!e || !e->nb || !e->built) return 0;
+    if (!e->sched_on) return ksp_engine_tile_pairs(e, t0, t1);
+    const size_t a0 = std::lower_bound(e->act_tid.begin(), e->act_tid.end(), t0) - e->act_tid.begin();
+    const size_t a1 = std::lower_bound(e->act_tid.begin(), e->act_tid.end(), t1) - e->act_tid.begin();
+    const u64 last = e->n_sources - (u64)(e->nb - 1) * TB;
+    u64 pairs = 0;
+    for (size_t i = a0; i < a1; ++i) {
+        const u32 I = e->act_rec[4 * i], J = e->act_rec[4 * i + 1];
+        const u64 nI = (I == e->nb - 1) ? last : TB, nJ = (J == e->nb - 1) ? last : TB;
+        pairs += (I == J) ? nI * (nI - 1) / 2 : nI * nJ;
     }
     return pairs;
 }
@@ -1655,22 +1888,61 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     dim3 block(JW * 64);
     a.blk_max = e->blk_max.as<u32>();
     a.inv = e->smap.as<u32>() + 3 * (((size_t)e->n_sources + 64) & ~(size_t)63);
+    a.sched = nullptr; a.act = nullptr; a.wg0 = 0; a.split0 = 0;
+    auto launch = [&](bool c16, dim3 grid, const JoinArgs& args) {
+        if (e->use_cells) {
+            if (e->weighted) { if (c16) hipLaunchKernelGGL((k_join<true, true, true>), grid, block, 0, st, args); else hipLaunchKernelGGL((k_join<true, false, true>), grid, block, 0, st, args); }
+            else { if (c16) hipLaunchKernelGGL((k_join<false, true, true>), grid, block, 0, st, args); else hipLaunchKernelGGL((k_join<false, false, true>), grid, block, 0, st, args); }
+        } else {
+            if (e->weighted) { if (c16) hipLaunchKernelGGL((k_join<true, true, false>), grid, block, 0, st, args); else hipLaunchKernelGGL((k_join<true, false, false>), grid, block, 0, st, args); }
+            else { if (c16) hipLaunchKernelGGL((k_join<false, true, false>), grid, block, 0, st, args); else hipLaunchKernelGGL((k_join<false, false, false>), grid, block, 0, st, args); }
+        }
+    };
     // HIP caps a launch at 2^32 threads: at most 4 Mi workgroups of 512 threads per launch (a larger grid
     // silently runs only part of its blocks — seen with 30.5 M tiles on MI355X / ROCm 7.2)
     const u64 kMaxTilesPerLaunch = 4ull << 20;
-    for (u64 chunk_begin = tile_begin; chunk_begin < tile_end; chunk_begin += kMaxTilesPerLaunch) {
+    size_t act0 = 0, act1 = 0;
+    if (e->sched_on) {
+        // work-list mode: the active tiles of [tile_begin, tile_end), each in its shares
+        act0 = std::lower_bound(e->act_tid.begin(), e->act_tid.end(), tile_begin) - e->act_tid.begin();
+        act1 = std::lower_bound(e->act_tid.begin(), e->act_tid.end(), tile_end) - e->act_tid.begin();
+        const u32 wgA = e->act_rec[4 * act0 + 2], wgB = e->act_rec[4 * act1 + 2];
+        const u32 spA = e->act_rec[4 * act0 + 3], spB = e->act_rec[4 * act1 + 3];
+        a.sched = e->d_wg.as<u32>();
+        a.act = e->d_act.as<u32>();
+        a.split0 = spA;
+        a.n_normal = 0; a.tail_sp = 1;
+        a.tailbuf = nullptr;
+        const u32 nsplit = spB - spA;
+        if (nsplit) {
+            if ((rc = e->tailbuf.ensure((size_t)nsplit * TB * TB * 4))) return rc;
+            a.tailbuf = e->tailbuf.as<u32>();
+            KSP_HIP(hipMemsetAsync(a.tailbuf, 0, (size_t)nsplit * TB * TB * 4, st));
+        }
+        for (int pass = 0; pass < (e->need32 ? 2 : 1); ++pass)
+            for (u64 w = wgA; w < wgB; w += kMaxTilesPerLaunch) {
+                a.wg0 = (u32)w;
+                launch(pass == 0, dim3((u32)std::min<u64>(kMaxTilesPerLaunch, wgB - w)), a);
+            }
+        if (nsplit) {
+            JoinArgs te = a;
+            te.sched = e->d_split.as<u32>();
+            for (u32 s0 = 0; s0 < nsplit; s0 += (u32)kMaxTilesPerLaunch) {   // (tail buffer slot = split index - split0)
+                te.split0 = spA + s0;
+                te.tailbuf = a.tailbuf + (size_t)s0 * (TB * TB);
+                hipLaunchKernelGGL(k_tail_emit, dim3(std::min<u32>((u32)kMaxTilesPerLaunch, nsplit - s0)), block, 0, st, te);
+            }
+        }
+        KSP_HIP(hipGetLastError());
+    }
+    for (u64 chunk_begin = tile_begin; !e->sched_on && chunk_begin < tile_end; chunk_begin += kMaxTilesPerLaunch) {
     const u64 chunk_end = std::min(tile_end, chunk_begin + kMaxTilesPerLaunch);
     a.tile_begin = chunk_begin;
     const u32 ntiles = (u32)(chunk_end - chunk_begin);
     // Tile splitting for small launches: when there are fewer tiles than workgroup slots on the chip,
     // every tile is cut into `sp` rank-range shares (partial counters are summed in a global buffer).
     u32 n_tail = 0, sp = 1;
-    if (e->slots == 0) {
-        int per_cu = 0, cus = 0;
-        KSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_join<false, true, true>, JW * 64, 0));
-        KSP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
-        e->slots = (u32)std::max(1, per_cu * cus);
-    }
+    if ((rc = query_slots(e))) return rc;
     // (Measured on C2, 3160 tiles on 768 slots: splitting the 88 "remainder" tiles does not pay — tiles
     //  finish at different times and the dispatcher back-fills — so only under-filled launches split.)
     if (!std::getenv("KSP_NO_TAIL_SPLIT")) {
@@ -1690,27 +1962,14 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     }
     dim3 grid(a.n_normal + n_tail * sp);
     // packed 16-bit counters wherever they are exact; 32-bit counters for the other tiles
-    if (e->use_cells) {
-        if (e->weighted) hipLaunchKernelGGL((k_join<true, true, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_join<false, true, true>), grid, block, 0, st, a);
-    } else {
-        if (e->weighted) hipLaunchKernelGGL((k_join<true, true, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_join<false, true, false>), grid, block, 0, st, a);
-    }
+    launch(true, grid, a);
     if (n_tail) hipLaunchKernelGGL(k_tail_emit, dim3(n_tail), block, 0, st, a);
     if (e->need32) {   // tiles whose two blocks both hold huge sketches: one workgroup per tile, no tail split
         JoinArgs b = a;
         b.n_normal = ntiles;
         b.tail_sp = 1;
         b.tailbuf = nullptr;
-        dim3 grid32(ntiles);
-        if (e->use_cells) {
-            if (e->weighted) hipLaunchKernelGGL((k_join<true, false, true>), grid32, block, 0, st, b);
-            else hipLaunchKernelGGL((k_join<false, false, true>), grid32, block, 0, st, b);
-        } else {
-            if (e->weighted) hipLaunchKernelGGL((k_join<true, false, false>), grid32, block, 0, st, b);
-            else hipLaunchKernelGGL((k_join<false, false, false>), grid32, block, 0, st, b);
-        }
+        launch(false, dim3(ntiles), b);
     }
     KSP_HIP(hipGetLastError());
     }   // launch chunks
@@ -1720,12 +1979,18 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     KSP_HIP(hipEventElapsedTime(&e->st.ms_join, e->ev[2], e->ev[3]));
     *h_count = *e->h_count;
     e->st.last_tiles = tile_end - tile_begin;
+    e->st.last_active_tiles = e->sched_on ? (u64)(act1 - act0) : tile_end - tile_begin;
     e->st.last_pairs = ksp_engine_tile_pairs(e, tile_begin, tile_end);
     e->st.last_edges = *h_count;
     {   // bytes the kernel streams from both block lists; self tiles read info [+ weight] only
         const u64 per = 4;   // only the 32-bit ranks are streamed; posting words are gathered on matches
         u64 bytes = 0;
-        for (u64 t = tile_begin; t < tile_end;) {
+        for (size_t i = act0; e->sched_on && i < act1; ++i) {   // work-list mode: the active tiles only
+            const u32 I = e->act_rec[4 * i], J = e->act_rec[4 * i + 1];
+            const u64 kI = e->h_blk_off[I + 1] - e->h_blk_off[I], kJ = e->h_blk_off[J + 1] - e->h_blk_off[J];
+            bytes += (J == I) ? kI * (e->weighted ? 8 : 4) : (kI + kJ) * per;
+        }
+        for (u64 t = tile_begin; !e->sched_on && t < tile_end;) {
             u32 I, J;
             tile_decode(t, e->nb, I, J);
             u64 stop = std::min(tile_row_start((u64)I + 1, e->nb), tile_end);

@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "ksp_pairwise_host", "ksp_free", "kspider_pairwise", "ksp_index_info", "ksp_format_float",
     "kspider_pairwise_sigs", "kspider_pairwise_bins",
     "ksp_engine_build_slice", "ksp_engine_slice_sizes", "ksp_engine_slice_export", "ksp_engine_assemble",
+    "ksp_engine_edge_bound",
 ]
 
 
@@ -35,7 +36,7 @@ class Stats(ctypes.Structure):
         ("n_block_keys", ctypes.c_uint64), ("n_tiles", ctypes.c_uint64), ("last_tiles", ctypes.c_uint64),
         ("last_pairs", ctypes.c_uint64), ("last_stream_bytes", ctypes.c_uint64), ("last_edges", ctypes.c_uint64),
         ("ms_build", ctypes.c_float), ("ms_join", ctypes.c_float), ("weighted", ctypes.c_int),
-        ("key_bits", ctypes.c_int),
+        ("key_bits", ctypes.c_int), ("n_active_tiles", ctypes.c_uint64), ("last_active_tiles", ctypes.c_uint64),
     ]
 
     def as_dict(self):
@@ -63,6 +64,8 @@ def lib():
         L.ksp_engine_num_tiles.restype = ctypes.c_uint64
         L.ksp_engine_num_tiles.argtypes = [ctypes.c_void_p]
         L.ksp_engine_tile_pairs.restype = ctypes.c_uint64
+        L.ksp_engine_edge_bound.restype = ctypes.c_uint64
+        L.ksp_engine_edge_bound.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
         L.ksp_engine_tile_pairs.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
         L.ksp_engine_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.ksp_engine_destroy.argtypes = [ctypes.c_void_p]
@@ -216,6 +219,10 @@ class Engine:
 
     def tile_pairs(self, t0: int, t1: int) -> int:
         return lib().ksp_engine_tile_pairs(self._h, t0, t1)
+
+    def edge_bound(self, t0: int, t1: int) -> int:
+        """Upper bound on the edges of tiles [t0, t1): source pairs of the tiles that share a key."""
+        return lib().ksp_engine_edge_bound(self._h, t0, t1)
 
     def join(self, t0: int, t1: int, d_edges_ptr: int, capacity: int, stream: int = 0) -> int:
         cnt = ctypes.c_uint64(0)
