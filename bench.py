@@ -134,17 +134,21 @@ def main():
     keys_d = torch.from_numpy(sk.keys.view(np.int64)).to(dev)
     stream = torch.cuda.current_stream(dev)
     eng = engine.Engine(local_rank)
-    eng.build_blocks(keys_d.data_ptr(), sk.offsets, stream=stream.cuda_stream)
-    T = eng.num_tiles
-    t0, t1 = kdist.tile_range(T, world, rank)
-    cap = int(min(eng.tile_pairs(t0, t1), 1 << 27)) + 1
+    sharded = world > 1 and os.environ.get("KSP_BENCH_REPLICATED_BUILD") != "1"
+    # one untimed build fixes this rank's tile range (equal estimated work per GPU; the data and
+    # therefore the cuts are the same in every step) and sizes the edge buffers
+    if sharded:
+        kdist.build_blocks_sharded(eng, keys_d.data_ptr(), sk.offsets, world, rank, dev, stream=stream.cuda_stream)
+    else:
+        eng.build_blocks(keys_d.data_ptr(), sk.offsets, stream=stream.cuda_stream)
+    cuts = eng.balanced_cuts(world)
+    t0, t1 = cuts[rank], cuts[rank + 1]
+    cap = int(min(eng.edge_bound(t0, t1), 1 << 27)) + 1
     edges_d = torch.empty((cap, 16), dtype=torch.uint8, device=dev)
-    host_cap = int(min(total_pairs, 1 << 27)) + 1
+    host_cap = int(min(eng.edge_bound(0, eng.num_tiles), total_pairs, 1 << 27)) + 1
     edges_h = torch.empty((host_cap, 16), dtype=torch.uint8).pin_memory() if rank == 0 else None
 
     stats = {"ms_join": 0.0, "ms_build": 0.0, "edges": 0, "stream_bytes": 0, "xchg_bytes": 0}
-
-    sharded = world > 1 and os.environ.get("KSP_BENCH_REPLICATED_BUILD") != "1"
 
     def step(record: bool):
         if sharded:   # stage 1 sharded by hash range + all-gather of the block-list slices
@@ -215,7 +219,7 @@ def main():
                                    f"weak scaling: sources = {base_n}*sqrt(n_gpus)",
                        "n_sources": n, "pairs": total_pairs, "nonzero_pairs": stats["edges"],
                        "checksum": stats["checksum"],
-                       "tiles": T,
+                       "tiles": int(eng.num_tiles), "active_tiles": int(eng.stats()["n_active_tiles"]),
                        "parallelism": (f"tile-range shard x{world}; stage 1 "
                                        + ("sharded by hash range + RCCL all-gather of the block-list slices "
                                           f"({stats['xchg_bytes'] / 1e6:.0f} MB received per rank)" if sharded

@@ -81,6 +81,9 @@ uint64_t ksp_engine_tile_pairs(const ksp_engine* e, uint64_t tile_begin, uint64_
 /* Tighter bound on the edges tiles [tile_begin, tile_end) can produce: the source pairs of the tiles
  * that share a key at all (stage 1 knows them; equals ksp_engine_tile_pairs in dense mode).       */
 uint64_t ksp_engine_edge_bound(const ksp_engine* e, uint64_t tile_begin, uint64_t tile_end);
+/* Tile ranges of equal estimated work for `nparts` GPUs: rank p joins tiles [cuts[p], cuts[p+1]).
+ * cuts has nparts + 1 entries; every rank computes the same cuts from the same block lists.       */
+int ksp_engine_balanced_cuts(const ksp_engine* e, uint32_t nparts, uint64_t* cuts);
 
 /* Stage 2: join tiles [tile_begin, tile_end) and append every pair with shared > 0 to
  * d_edges (device buffer of `capacity` edges; order unspecified).  *h_count receives the
@@ -92,10 +95,16 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
 int ksp_engine_get_stats(const ksp_engine* e, ksp_stats* out);
 
 /* ---- stage 1 sharded over GPUs (one process per GPU) ---------------------------------------
- * Every rank holds the full sketch set; rank `part` of `nparts` builds the block lists of the
- * keys in its 1/nparts share of the hash range only (ksp_engine_build_slice), the slices are
- * exchanged by the caller (all-gather over RCCL: kspider_amd/dist.py), and every rank turns the
- * gathered slices into the full block lists (ksp_engine_assemble) before ksp_engine_join.
+ * Every rank holds the full sketch set; rank `part` of `nparts` sorts and prunes the keys of its
+ * 1/nparts share of the hash range only (ksp_engine_build_slice).  The engine orders the sources by a
+ * label derived from the shared keys, so the ranks first combine their labels (ksp_engine_slice_labels,
+ * element-wise MIN all-reduce of n_sources uint32 over RCCL, ksp_engine_slice_finish) and then build
+ * their slices of the block lists in that common order.  The slices are exchanged by the caller
+ * (all-gather: kspider_amd/dist.py) and every rank turns the gathered slices into the full block lists
+ * (ksp_engine_assemble) before ksp_engine_join.
+ *   slice_labels: copies the slice's n_sources labels into a device buffer.
+ *   slice_finish: d_labels = the combined labels (device; NULL keeps the slice's own: single slice
+ *                tests only — every rank must use the same labels).
  *   slice_sizes: out[0] padded list length L (uint32 entries of d_brk / d_info / d_bw),
  *                out[1] distinct keys, out[2] 128-bit posting masks, out[3] block keys.
  *   slice_export: copies the slice into caller buffers (device pointers): d_brk/d_info[/d_bw] L
@@ -106,6 +115,8 @@ int ksp_engine_get_stats(const ksp_engine* e, ksp_stats* out);
 int ksp_engine_build_slice(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights,
                            const uint64_t* h_offsets, uint32_t n_sources, int key_bits, uint32_t part,
                            uint32_t nparts, void* stream);
+int ksp_engine_slice_labels(ksp_engine* e, uint32_t* d_labels, void* stream);
+int ksp_engine_slice_finish(ksp_engine* e, const uint32_t* d_labels, void* stream);
 int ksp_engine_slice_sizes(const ksp_engine* e, uint64_t out[4]);
 int ksp_engine_slice_export(ksp_engine* e, uint32_t* d_brk, uint32_t* d_info, uint32_t* d_bw, uint32_t* d_blk_raw,
                             uint32_t* d_blk_pos, void* d_big, void* stream);

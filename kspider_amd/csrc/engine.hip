@@ -1176,6 +1176,7 @@ struct ksp_engine {
     u64 max_key = 0;
     bool have_max_key = false;
     bool slice_ready = false;
+    int slice_phase = 0;          // 1: build_slice done, waiting for ksp_engine_slice_finish
     u64 slice_hdr[4] = {0, 0, 0, 0};   // padded length, distinct keys (U), big postings, block keys
     u32 ncell = ksp::NP;          // fine rank cells per block (power of two)
     bool use_cells = true;        // rank-aligned cell join (KSP_JOIN=window selects the sliding-window merge)
@@ -1208,7 +1209,9 @@ namespace ksp {
 static inline unsigned grid_for(u64 n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
 template <bool W>
-static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStream_t st) {
+static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStream_t st, const int phase) {
+    // phase 0: the whole of stage 1;  1: up to the source labels (key-range slice, before the labels of all
+    // slices are combined);  2: the rest (source order from the final labels, block lists)
     typedef typename std::conditional<W, u64, u32>::type V;
     const u64 n = e->n_entries;
     const u32 N = e->n_sources, nb = e->nb;
@@ -1227,6 +1230,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if ((rc = e->part.ensure(((size_t)nb + 1) * ((size_t)e->ncell + 1) * 4))) return rc;
     if ((rc = e->blk_max.ensure(((size_t)nb + 2) * 4))) return rc;
     if ((rc = e->scalars.ensure(128))) return rc;
+    if ((rc = e->R1.ensure((n + 4) * 4))) return rc;
 
     u64* KA = e->KA.as<u64>();
     V* VA = e->VA.as<V>();
@@ -1237,9 +1241,21 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     u32* blk_raw = e->blk_raw.as<u32>();
     u32* blk_pos = e->blk_pos.as<u32>();
     const unsigned bs = 256;
+    u32* rank1 = e->R1.as<u32>();
+    const size_t NN = ((size_t)N + 64) & ~(size_t)63;
+    if ((rc = e->smap.ensure(6 * NN * 4))) return rc;
+    // per-source maps: [0] label, [1] iota, [2] sorted labels, [3] order (= engine index -> source id),
+    // [4] newidx (source id -> engine index), [5] bound of a source's pair counters
+    u32* sm = e->smap.as<u32>();
+    u32 *label = sm, *iota = sm + NN, *labs = sm + 2 * NN, *order = sm + 3 * NN, *newidx = sm + 4 * NN, *sbound = sm + 5 * NN;
+    const bool reorder = e->reorder;
+    int bbits = 1;
+    while ((1u << bbits) < nb) ++bbits;
+    size_t tb = 0;
+    u64 m = e->n_kept;   // (phase 2: set by phase 1)
+    if (phase != 2) {
 
     // key range (one 8-byte D2H, unless the caller passed key_bits)
-    size_t tb = 0;
     if (e->key_bits <= 0) {
         KSP_HIP(hipMemsetAsync(scal, 0, 8, st));
         hipLaunchKernelGGL(k_max_last, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_keys, d_off, (unsigned long long*)scal, N);
@@ -1253,15 +1269,6 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         e->key_bits = bits;
     }
     const int kbits = e->key_bits;
-    int bbits = 1;
-    while ((1u << bbits) < nb) ++bbits;
-
-    // per-source maps: [0] label, [1] iota, [2] sorted labels, [3] order (= engine index -> source id),
-    // [4] newidx (source id -> engine index), [5] bound of a source's pair counters
-    const size_t NN = ((size_t)N + 64) & ~(size_t)63;
-    if ((rc = e->smap.ensure(6 * NN * 4))) return rc;
-    u32* sm = e->smap.as<u32>();
-    u32 *label = sm, *iota = sm + NN, *labs = sm + 2 * NN, *order = sm + 3 * NN, *newidx = sm + 4 * NN, *sbound = sm + 5 * NN;
     if (W || e->nparts == 1)   // (weighted slices still need the per-source weight sums of all entries)
         hipLaunchKernelGGL((k_tag<W>), dim3(N), dim3(256), 0, st, d_off, d_w, W ? nullptr : (u32*)VA,
                            W ? (u64*)VA : nullptr, sbound);
@@ -1269,7 +1276,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, iota, N);
     hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, N);    // identity until the labels are known
     hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, newidx, N);
-    const bool reorder = e->reorder && e->nparts == 1;
+    hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, label, N);
     KSP_HIP(hipMemsetAsync(e->blk_max.p, 0, ((size_t)nb + 1) * 4, st));
     if (!reorder) hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
     // slice mode (multi-GPU build): keep only the entries of this part's key range — one contiguous
@@ -1306,7 +1313,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         tags_in = e->FT.as<V>();
     }
     e->n_kept = 0;
-    if (nw == 0) return KSP_OK;   // (slice mode only) no key of this range
+    m = 0;
+    if (nw == 0) return KSP_OK;   // (slice mode only) no key of this range: labels stay the identity
     // sort 1: all entries by the top 32 significant key bits (payload = tag [+weight]):
     // d_keys,VA -> KA,VB; then order the rare mixed runs by the full key (k_fix_runs)
     // (rocPRIM 4.2 / ROCm 7.2 mis-sorts 64-bit keys on any bit range [b > 0, 64) below ~1M items —
@@ -1332,9 +1340,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                            d_ovf);
     }
     // singleton pruning + dense ranks of the kept keys (packed counters, one scan):  KA,VB -> R1 (ranks), VA (tags)
-    if ((rc = e->R1.ensure((n + 4) * 4))) return rc;
     u64* ps = (u64*)e->KB.p;               // n packed prefix sums
-    u32* rank1 = e->R1.as<u32>();
     {
         auto pf = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u64>(0), PruneFn{KA, nw});
         tb = 0;
@@ -1345,15 +1351,19 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     hipLaunchKernelGGL((k_prune_scatter<V>), dim3(grid_for(nw, bs)), dim3(bs), 0, st, VB, ps, VA, rank1, scal, nw);
     KSP_HIP(hipMemcpyAsync(e->h_scal + 6, scal + 6, 8, hipMemcpyDeviceToHost, st));
     KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
-    const u64 m = e->h_scal[6];
+    m = e->h_scal[6];
     e->n_kept = m;
-    if (m == 0) return KSP_OK;             // no key is shared by two sources: no pair at all
-    if (reorder) {
-        // order the sources by (label, id): label = smallest source id among the holders of its shared keys
+    if (m == 0 && phase == 0) return KSP_OK;   // no key is shared by two sources: no pair at all
+    if (reorder && m) {
+        // label = smallest source id among the holders of a source's shared keys
         u32* first = (u32*)e->KB.p;        // U entries (the packed prefix sums are dead)
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, label, N);
         hipLaunchKernelGGL(k_rank_first, dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, first, m);
         hipLaunchKernelGGL((k_label<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, VA, first, label, m);
+    }
+    if (phase == 1) return KSP_OK;
+    }   // phase != 2
+    if (reorder) {
+        // order the sources by (label, id) and move the kept entries to the new indices
         int lbits = 1;
         while (lbits < 32 && (N >> lbits)) ++lbits;
         tb = 0;
@@ -1361,9 +1371,10 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         if ((rc = e->tmp.ensure(tb))) return rc;
         KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, label, labs, iota, order, (size_t)N, 0, lbits, st));
         hipLaunchKernelGGL(k_perm, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, newidx, N);
-        hipLaunchKernelGGL((k_retag<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, VA, newidx, m);
+        if (m) hipLaunchKernelGGL((k_retag<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, VA, newidx, m);
         hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
     }
+    if (m == 0) return KSP_OK;
     // sort 2: stable by block id (bits [8, 8+bbits) of the tag), payload = rank:  VA,rank1 -> VB,rk2
     u32* rk2 = (u32*)KA;                   // KA (sorted keys) is dead from here on
     tb = 0;
@@ -1543,7 +1554,8 @@ static int build_schedule(ksp_engine* e) {
         }
     }
     const size_t A = e->act_tid.size();
-    const u64 target = std::max<u64>(total / ((u64)e->slots * 3) + 1, 20000);
+    // (a sharded job joins 1/nparts of the list per GPU: size the shares for that)
+    const u64 target = std::max<u64>(total / ((u64)e->slots * 3 * std::max<u32>(1, e->nparts)) + 1, 20000);
     // pass 2: shares
     std::vector<u32> wg;
     wg.reserve(A + (size_t)e->slots * 4);
@@ -1594,7 +1606,7 @@ static int finish_build(ksp_engine* e) {
 
 // common front end of build_blocks / build_slice
 static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights, const uint64_t* h_offsets,
-                        uint32_t n_sources, int key_bits, u32 part, u32 nparts, hipStream_t st) {
+                        uint32_t n_sources, int key_bits, u32 part, u32 nparts, hipStream_t st, const bool slice = false) {
     if (!e || !h_offsets) { set_error("build: NULL argument"); return KSP_E_ARG; }
     if (nparts == 0 || part >= nparts) { set_error("build: bad part / nparts"); return KSP_E_ARG; }
     KSP_HIP(hipSetDevice(e->device));
@@ -1647,7 +1659,8 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     if ((rc = e->blk_max.ensure(((size_t)e->nb + 2) * 4))) return rc;
     if (const char* ro = std::getenv("KSP_REORDER")) e->reorder = std::atoi(ro) != 0;   // diagnostic / tests
     for (int attempt = 0; attempt < 2; ++attempt) {
-        rc = e->weighted ? build_impl<true>(e, d_keys, d_weights, st) : build_impl<false>(e, d_keys, d_weights, st);
+        const int phase = slice ? 1 : 0;   // a slice stops at the source labels (ksp_engine_slice_finish does the rest)
+        rc = e->weighted ? build_impl<true>(e, d_keys, d_weights, st, phase) : build_impl<false>(e, d_keys, d_weights, st, phase);
         if (rc) return rc;
         KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 64, hipMemcpyDeviceToHost, st));
         KSP_HIP(hipStreamSynchronize(st));
@@ -1657,7 +1670,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
         e->full_sort = true;
     }
     e->have_bits = false;
-    if (nparts == 1 && e->n_kept) {   // the work list of the join (slices: after the assemble)
+    if (!slice && e->n_kept) {   // the work list of the join (slices: after the assemble)
         e->h_scal_words = e->h_scal[1];
         e->h_scal_keys = e->h_scal[2];
         if ((rc = launch_sched_kernels(e, st))) return rc;
@@ -1686,10 +1699,41 @@ int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_
 int ksp_engine_build_slice(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights,
                            const uint64_t* h_offsets, uint32_t n_sources, int key_bits, uint32_t part,
                            uint32_t nparts, void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    int rc = build_common(e, d_keys, d_weights, h_offsets, n_sources, key_bits, part, nparts, st);
+    int rc = build_common(e, d_keys, d_weights, h_offsets, n_sources, key_bits, part, nparts, (hipStream_t)stream, true);
     if (rc) return rc;
+    e->slice_phase = 1;
+    return KSP_OK;
+}
+
+static u32* label_array(ksp_engine* e) { return e->smap.as<u32>(); }   // [0] of the per-source maps
+
+int ksp_engine_slice_labels(ksp_engine* e, uint32_t* d_labels, void* stream) {
+    if (!e || !d_labels) { set_error("slice_labels: NULL argument"); return KSP_E_ARG; }
+    if (e->slice_phase != 1) { set_error("slice_labels: build_slice has not been run"); return KSP_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    KSP_HIP(hipSetDevice(e->device));
+    if (e->n_entries == 0 || e->nb == 0) {   // nothing was built: identity labels
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(std::max<u32>(1, e->n_sources), 256)), dim3(256), 0, st, d_labels, e->n_sources);
+    } else {
+        KSP_HIP(hipMemcpyAsync(d_labels, label_array(e), (size_t)e->n_sources * 4, hipMemcpyDeviceToDevice, st));
+    }
+    KSP_HIP(hipStreamSynchronize(st));
+    return KSP_OK;
+}
+
+int ksp_engine_slice_finish(ksp_engine* e, const uint32_t* d_labels, void* stream) {
+    if (!e) { set_error("slice_finish: NULL argument"); return KSP_E_ARG; }
+    if (e->slice_phase != 1) { set_error("slice_finish: build_slice has not been run"); return KSP_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    KSP_HIP(hipSetDevice(e->device));
+    e->slice_phase = 0;
     if (e->n_entries == 0 || e->nb == 0) { e->slice_ready = true; return KSP_OK; }
+    int rc;
+    KSP_HIP(hipEventRecord(e->ev[0], st));
+    if (d_labels) KSP_HIP(hipMemcpyAsync(label_array(e), d_labels, (size_t)e->n_sources * 4, hipMemcpyDeviceToDevice, st));
+    rc = e->weighted ? build_impl<true>(e, nullptr, nullptr, st, 2) : build_impl<false>(e, nullptr, nullptr, st, 2);
+    if (rc) return rc;
+    KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 64, hipMemcpyDeviceToHost, st));
     if (e->n_kept == 0) {
         // empty slice: valid (all-pad) lists so that export / assemble need no special case
         if ((rc = e->blk_raw.ensure(((size_t)e->nb + 2) * 4))) return rc;
@@ -1699,14 +1743,19 @@ int ksp_engine_build_slice(ksp_engine* e, const uint64_t* d_keys, const uint32_t
         const u64 lpad = (u64)e->nb * (WIN + 4) + 4 * WIN;
         hipLaunchKernelGGL(k_fill, dim3(grid_for(lpad, 256)), dim3(256), 0, st, e->bkeys.as<u32>(), PAD, lpad);
         KSP_HIP(hipMemcpyAsync(e->h_scal + 3, e->scalars.as<u64>() + 3, 8, hipMemcpyDeviceToHost, st));
-        KSP_HIP(hipStreamSynchronize(st));
-        e->slice_hdr[0] = e->h_scal[3];
+    }
+    KSP_HIP(hipEventRecord(e->ev[1], st));
+    KSP_HIP(hipStreamSynchronize(st));
+    float ms = 0;
+    KSP_HIP(hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
+    e->st.ms_build += ms;
+    e->slice_hdr[0] = e->h_scal[3];           // padded length
+    if (e->n_kept == 0) {
         e->slice_hdr[1] = e->slice_hdr[2] = e->slice_hdr[3] = 0;
     } else {
-        e->slice_hdr[0] = e->h_scal[3];   // padded length
-        e->slice_hdr[1] = e->h_scal[2];   // distinct keys (U)
-        e->slice_hdr[2] = e->h_scal[7];   // big postings
-        e->slice_hdr[3] = e->h_scal[1];   // block keys
+        e->slice_hdr[1] = e->h_scal[2];       // distinct keys (U)
+        e->slice_hdr[2] = e->h_scal[7];       // big postings
+        e->slice_hdr[3] = e->h_scal[1];       // block keys
     }
     e->slice_ready = true;
     return KSP_OK;
@@ -1850,6 +1899,28 @@ uint64_t ksp_engine_edge_bound(const ksp_engine* e, uint64_t t0, uint64_t t1) {
         pairs += (I == J) ? nI * (nI - 1) / 2 : nI * nJ;
     }
     return pairs;
+}
+
+int ksp_engine_balanced_cuts(const ksp_engine* e, uint32_t nparts, uint64_t* cuts) {
+    if (!e || !cuts || nparts == 0) { set_error("balanced_cuts: bad argument"); return KSP_E_ARG; }
+    if (!e->built) { set_error("balanced_cuts: build_blocks / assemble has not been run"); return KSP_E_ARG; }
+    const u64 T = ksp_engine_num_tiles(e);
+    if (!e->sched_on) {   // dense mode: equal tile counts
+        for (u32 p = 0; p <= nparts; ++p) cuts[p] = (T * p) / nparts;
+        return KSP_OK;
+    }
+    // work-list mode: equal numbers of workgroups (shares are sized by estimated work), whole tiles only
+    const size_t A = e->act_tid.size();
+    const u64 W = e->act_rec[4 * A + 2];
+    cuts[0] = 0;
+    size_t i = 0;
+    for (u32 p = 1; p < nparts; ++p) {
+        const u64 want = (W * p) / nparts;
+        while (i < A && e->act_rec[4 * i + 2] < want) ++i;
+        cuts[p] = i < A ? e->act_tid[i] : T;
+    }
+    cuts[nparts] = T;
+    return KSP_OK;
 }
 
 int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_edge* d_edges, uint64_t capacity,

@@ -39,7 +39,8 @@ def build_blocks_sharded(eng, d_keys_ptr: int, h_offsets: np.ndarray, world_size
     """Stage 1 sharded over the ranks (every rank holds the full sketch set).
 
     Rank r builds the block-list slices of its 1/world share of the hash range
-    (`Engine.build_slice`), the slices are all-gathered (RCCL `all_gather_into_tensor`; host tensors
+    (`Engine.build_slice` / `slice_finish`, after a MIN all-reduce of the source labels that fixes the
+    common source order), the slices are all-gathered (RCCL `all_gather_into_tensor`; host tensors
     with gloo), and every rank assembles the full lists (`Engine.assemble`).  With world_size 1 this
     is a plain `build_blocks`.  Returns the bytes this rank received in the exchange.
     """
@@ -49,6 +50,16 @@ def build_blocks_sharded(eng, d_keys_ptr: int, h_offsets: np.ndarray, world_size
     eng.build_slice(d_keys_ptr, h_offsets, rank, world_size, d_weights_ptr=d_weights_ptr, stream=stream)
     on_gpu = dist.get_backend(group) == "nccl"
     comm_dev = device if on_gpu else torch.device("cpu")
+    # common source order: element-wise MIN of the ranks' labels (n_sources x 4 bytes)
+    labels = torch.empty(len(h_offsets) - 1, dtype=torch.int32, device=device)
+    eng.slice_labels(labels.data_ptr(), stream=stream)
+    if on_gpu:
+        dist.all_reduce(labels, op=dist.ReduceOp.MIN, group=group)
+    else:
+        lab_h = labels.cpu()
+        dist.all_reduce(lab_h, op=dist.ReduceOp.MIN, group=group)
+        labels.copy_(lab_h)
+    eng.slice_finish(labels.data_ptr(), stream=stream)
     mine = torch.from_numpy(eng.slice_sizes().astype(np.int64)).to(comm_dev)
     all_sz = torch.zeros(4 * world_size, dtype=torch.int64, device=comm_dev)
     if on_gpu:

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "ksp_pairwise_host", "ksp_free", "kspider_pairwise", "ksp_index_info", "ksp_format_float",
     "kspider_pairwise_sigs", "kspider_pairwise_bins",
     "ksp_engine_build_slice", "ksp_engine_slice_sizes", "ksp_engine_slice_export", "ksp_engine_assemble",
-    "ksp_engine_edge_bound",
+    "ksp_engine_edge_bound", "ksp_engine_slice_labels", "ksp_engine_slice_finish", "ksp_engine_balanced_cuts",
 ]
 
 
@@ -65,6 +65,7 @@ def lib():
         L.ksp_engine_num_tiles.argtypes = [ctypes.c_void_p]
         L.ksp_engine_tile_pairs.restype = ctypes.c_uint64
         L.ksp_engine_edge_bound.restype = ctypes.c_uint64
+        L.ksp_engine_balanced_cuts.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
         L.ksp_engine_edge_bound.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
         L.ksp_engine_tile_pairs.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
         L.ksp_engine_create.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
@@ -79,6 +80,8 @@ def lib():
                                              ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32,
                                              ctypes.c_void_p]
         L.ksp_engine_slice_sizes.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        L.ksp_engine_slice_labels.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.ksp_engine_slice_finish.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.ksp_engine_slice_export.argtypes = [ctypes.c_void_p] + [ctypes.c_void_p] * 7
         L.ksp_engine_assemble.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,
@@ -195,6 +198,14 @@ class Engine:
                                             h_offsets.ctypes.data, h_offsets.size - 1, key_bits, part, nparts,
                                             stream or None))
 
+    def slice_labels(self, d_labels: int, stream: int = 0):
+        """Copy the slice's source labels (n_sources uint32) into a device buffer."""
+        _check(lib().ksp_engine_slice_labels(self._h, d_labels, stream or None))
+
+    def slice_finish(self, d_labels: int = 0, stream: int = 0):
+        """Second half of a slice build, in the source order given by the combined labels."""
+        _check(lib().ksp_engine_slice_finish(self._h, d_labels or None, stream or None))
+
     def slice_sizes(self) -> np.ndarray:
         out = (ctypes.c_uint64 * 4)()
         _check(lib().ksp_engine_slice_sizes(self._h, out))
@@ -219,6 +230,12 @@ class Engine:
 
     def tile_pairs(self, t0: int, t1: int) -> int:
         return lib().ksp_engine_tile_pairs(self._h, t0, t1)
+
+    def balanced_cuts(self, nparts: int) -> list:
+        """Tile ranges of equal estimated work: rank p joins tiles [cuts[p], cuts[p + 1])."""
+        out = (ctypes.c_uint64 * (nparts + 1))()
+        _check(lib().ksp_engine_balanced_cuts(self._h, nparts, out))
+        return [int(x) for x in out]
 
     def edge_bound(self, t0: int, t1: int) -> int:
         """Upper bound on the edges of tiles [t0, t1): source pairs of the tiles that share a key."""

@@ -12,9 +12,13 @@ nb = (N + 127) // 128
 for it in range(2):
     t = time.time(); e.build_blocks(keys_d.data_ptr(), sk.offsets); torch.cuda.synchronize(); t_full = time.time() - t
 sizes = []; rows = []
+# the ranks' MIN all-reduce of the source labels, emulated on one GPU
+labels = torch.full((N,), 2**31 - 1, dtype=torch.int32, device=dev); lab = torch.empty_like(labels)
+for p in range(G):
+    e.build_slice(keys_d.data_ptr(), sk.offsets, p, G); e.slice_labels(lab.data_ptr()); labels = torch.minimum(labels, lab)
 for p in range(G):
     for it in range(2 if p == 0 else 1):
-        t = time.time(); e.build_slice(keys_d.data_ptr(), sk.offsets, p, G); torch.cuda.synchronize(); t_slice = time.time() - t
+        torch.cuda.synchronize(); t = time.time(); e.build_slice(keys_d.data_ptr(), sk.offsets, p, G); e.slice_finish(labels.data_ptr()); torch.cuda.synchronize(); t_slice = time.time() - t
     sz = e.slice_sizes(); sizes.append(sz)
     L, nbig = int(sz[0]), int(sz[2])
     r = [torch.zeros(L, dtype=torch.int32, device=dev), torch.zeros(L, dtype=torch.int32, device=dev), None,
@@ -35,7 +39,7 @@ for it in range(3):
     e.assemble(sizes, brk.data_ptr(), info.data_ptr(), 0, ls, raw.data_ptr(), pos.data_ptr(), big.data_ptr(), bs)
     torch.cuda.synchronize(); t_asm = time.time() - t
 print(f"assemble {t_asm*1e3:.2f} ms; gathered bytes per rank {(brk.numel()+info.numel())*4*(G-1)/G/1e6:.0f} MB; block keys {e.stats()['n_block_keys']}")
-T = e.num_tiles; t0, t1 = 0, T // G
+T = e.num_tiles; cuts = e.balanced_cuts(G); print('cuts', cuts, 'active', e.stats()['n_active_tiles']); t0, t1 = cuts[G // 2], cuts[G // 2 + 1]
 cap = 1 << 24; de = torch.empty((cap, 16), dtype=torch.uint8, device=dev)
 for it in range(2):
     cnt = e.join(t0, t1, de.data_ptr(), cap); st = e.stats()
