@@ -10,6 +10,20 @@ from kspider_amd import engine, synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["default", "no_reorder", "dense_walk"])
+def mode(request, monkeypatch):
+    """Every case runs three ways: as shipped (sources reordered by shared-key label, join over the
+    work list of active tiles), with the caller's source order (KSP_REORDER=0), and with the
+    reordering but a plain walk over all tiles (KSP_NO_SCHED=1)."""
+    monkeypatch.delenv("KSP_REORDER", raising=False)
+    monkeypatch.delenv("KSP_NO_SCHED", raising=False)
+    if request.param == "no_reorder":
+        monkeypatch.setenv("KSP_REORDER", "0")
+    elif request.param == "dense_walk":
+        monkeypatch.setenv("KSP_NO_SCHED", "1")
+    return request.param
+
+
 def _check(sk, oracle, weights=None):
     edges, st = engine.pairwise_host(sk.keys, sk.offsets, weights)
     ref = oracle.brute_pairs(sk.keys, sk.offsets)
@@ -128,3 +142,18 @@ def test_rank_skew_takes_the_oversized_cell_path(oracle_lib):
         runs.append(np.unique(np.concatenate([wide, band])))
     sk = synth.from_runs(runs)
     _check(sk, oracle_lib)
+
+
+def test_label_structures(oracle_lib):
+    """Inputs that stress the source ordering: a chain (i shares one key with i + 1 only), one key held
+    by every source, sources without any shared key, and two interleaved families."""
+    n = 400
+    runs = []
+    for i in range(n):
+        own = [10_000_000 + 17 * i, 20_000_000 + 31 * i]          # unique to i
+        chain = [1_000 + i, 1_000 + i + 1]                          # shared with i - 1 and i + 1
+        fam = [5_000_000 + (i % 2) * 1000 + k for k in range(6)]    # two families, interleaved ids
+        hub = [42] if i % 3 else []                                 # one key in two thirds of the sources
+        runs.append(sorted(set(own + chain + fam + hub)))
+    runs += [[90_000_000 + i] for i in range(40)]                   # loners
+    _check(synth.from_runs(runs), oracle_lib)

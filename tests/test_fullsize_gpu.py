@@ -68,3 +68,27 @@ def test_overflow_is_reported_not_silent(c2):
     with pytest.raises(engine.KspError) as ei:
         e.join(0, e.num_tiles, de.ptr.value, 1000)
     assert ei.value.code == engine.KSP_E_OVERFLOW
+
+
+def test_work_list_and_balanced_cuts(c2):
+    """Stage 1 knows which block pairs share a key: most tiles of C2 are skipped, the edge bound is
+    tighter than the pair count, and the per-GPU tile ranges of equal work unite to the full result."""
+    sk, dk, e, de, cap = c2
+    T = e.num_tiles
+    full = _join(e, de, cap, 0, T)
+    st = e.stats()
+    assert st["n_tiles"] == T and 0 < st["n_active_tiles"] < T // 4
+    assert st["last_active_tiles"] == st["n_active_tiles"]
+    assert len(full) <= e.edge_bound(0, T) <= e.tile_pairs(0, T)
+    for world in (2, 3, 8):
+        cuts = e.balanced_cuts(world)
+        assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == T
+        assert all(cuts[i] <= cuts[i + 1] for i in range(world))
+        parts, active = [], 0
+        for r in range(world):
+            parts.append(_join(e, de, cap, cuts[r], cuts[r + 1]))
+            assert len(parts[-1]) <= e.edge_bound(cuts[r], cuts[r + 1])
+            active += e.stats()["last_active_tiles"]
+        assert active == st["n_active_tiles"]
+        parts = np.sort(np.concatenate(parts), order=["source_1", "source_2"])
+        assert (parts == full).all()
