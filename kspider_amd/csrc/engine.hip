@@ -552,6 +552,7 @@ struct JoinArgs {
     u32 n_normal;       // blocks [0, n_normal) own one tile each; the rest split the tail tiles
     u32 tail_sp;        // workgroups per tail tile (each takes 1/tail_sp of the rank range)
     u32* tailbuf;       // n_tail x TB*TB 32-bit counters the tail workgroups add into
+    u32* tail_done;     // work-list mode: per split tile, the shares that have added their counters
     u32 dbg;            // timing-only ablation switches (-DKSP_ABLATE builds + KSP_DEBUG_ABLATE; results are wrong when set)
 };
 
@@ -668,7 +669,8 @@ __device__ inline uint4 posting_mask(u32 inf, const uint4* __restrict__ bigmask)
 // block (source reordering), so postings of 5 .. 40 sources are the common case.
 // Row form (fuller masks): lanes own the columns (lane, lane + 64), rows come from a scalar walk
 // over the bits of mask A; every LDS atomic touches 64 consecutive counters (conflict free).
-constexpr u32 DENSE_MAX = 48;
+constexpr u32 DENSE_MAX = 48;        // two different postings (cA x cB grid)
+constexpr u32 DENSE_MAX_SELF = 128;  // one posting against itself (triangle: half the patches)
 __device__ inline void mask_to_list(unsigned char* l, const u32 m0, const u32 m1, const u32 m2, const u32 m3, const int lane) {
     const u32 below_lo = __builtin_amdgcn_mbcnt_hi(m1, __builtin_amdgcn_mbcnt_lo(m0, 0));   // members among columns < lane
     const u32 below_hi = __builtin_amdgcn_mbcnt_hi(m3, __builtin_amdgcn_mbcnt_lo(m2, 0));   // ... among columns 64 .. 64 + lane - 1
@@ -684,7 +686,7 @@ __device__ inline void add_masks(u32* S, unsigned char* lst, uint4 mA, uint4 mB,
     const u32 b2 = __builtin_amdgcn_readfirstlane(mB.z), b3 = __builtin_amdgcn_readfirstlane(mB.w);
     const u32 ca = (u32)(__popc(a0) + __popc(a1) + __popc(a2) + __popc(a3));
     const u32 cb = SELF ? ca : (u32)(__popc(b0) + __popc(b1) + __popc(b2) + __popc(b3));
-    if (cb <= DENSE_MAX) {
+    if (cb <= (SELF ? DENSE_MAX_SELF : DENSE_MAX)) {
         unsigned char* la = lst;
         unsigned char* lb = SELF ? lst : lst + TB;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1124,6 +1126,16 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
             const u32 v = C16 ? ((S[idx >> 1] >> ((idx & 1) * 16)) & 0xFFFFu) : S[idx];
             if (v) atomicAdd(&dst[idx], v);
         }
+        if (!a.tail_done) return;   // (dense mode: k_tail_emit compacts the buffer)
+        // work-list mode: the share that finishes last turns the summed counters into edges
+        __shared__ u32 s_last;
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(&a.tail_done[tail_id], 1u) == sp - 1 ? 1u : 0u;
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+        emit_tile(a, I, J, tid, lane, [&](int idx) { return __hip_atomic_load(&dst[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
         return;
     }
     // flush: compact the non-zero counters of the tile into edges
@@ -1134,12 +1146,7 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
 __global__ __launch_bounds__(JW * 64) void k_tail_emit(JoinArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     u32 I, J;
-    if (a.sched) {   // work-list mode: a.sched = the split tiles of the work list (indices into a.act)
-        const u32* t = a.act + 4 * (size_t)a.sched[a.split0 + blockIdx.x];
-        I = t[0]; J = t[1];
-    } else {
-        tile_decode(a.tile_begin + a.n_normal + blockIdx.x, a.nb, I, J);
-    }
+    tile_decode(a.tile_begin + a.n_normal + blockIdx.x, a.nb, I, J);
     const u32* src = a.tailbuf + (size_t)blockIdx.x * (TB * TB);
     emit_tile(a, I, J, tid, lane, [&](int idx) { return src[idx]; });
 }
@@ -1195,8 +1202,7 @@ struct ksp_engine {
     bool have_bits = false;       // tbits / dwork hold this build's tile bitmap and diagonal work
     std::vector<u64> act_tid;     // active tiles (row-major tile ids, ascending)
     std::vector<u32> act_rec;     // per active tile: I, J, first workgroup, split index (+ one sentinel record)
-    std::vector<u32> split_list;  // active-tile indices of the tiles cut into several shares
-    ksp::Buf tbits, dwork, d_act, d_wg, d_split;
+    ksp::Buf tbits, dwork, d_act, d_wg;
     unsigned long long* h_count = nullptr;   // pinned
     u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
     u64 h_scal_words = 0, h_scal_keys = 0;   // list words / distinct shared keys of the lists being finished
@@ -1493,7 +1499,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
-                        &e->d_wg, &e->d_split};
+                        &e->d_wg};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
@@ -1517,7 +1523,7 @@ static int query_slots(ksp_engine* e) {
 // pair update of a diagonal tile, ~2000 per workgroup (zeroing and flushing the counter tile).
 static int build_schedule(ksp_engine* e) {
     e->sched_on = false;
-    e->act_tid.clear(); e->act_rec.clear(); e->split_list.clear();
+    e->act_tid.clear(); e->act_rec.clear();
     e->st.n_active_tiles = e->st.n_tiles;
     if (!e->have_bits) return KSP_OK;
     const u32 nb = e->nb;
@@ -1568,7 +1574,7 @@ static int build_schedule(ksp_engine* e) {
         sp = std::min<u64>(std::max<u64>(sp, 1), 32);
         u32* r = &e->act_rec[4 * i];
         r[0] = I; r[1] = J; r[2] = (u32)wg.size(); r[3] = nsplit;
-        if (sp > 1) { e->split_list.push_back((u32)i); ++nsplit; }
+        if (sp > 1) ++nsplit;
         for (u64 q = 0; q < sp; ++q) wg.push_back((u32)i);
         if (wg.size() > 0x7FFFFFF0ull) return KSP_OK;   // (absurdly many shares: stay dense)
     }
@@ -1576,11 +1582,8 @@ static int build_schedule(ksp_engine* e) {
     r[0] = 0; r[1] = 0; r[2] = (u32)wg.size(); r[3] = nsplit;
     if ((rc = e->d_act.ensure(e->act_rec.size() * 4))) return rc;
     if ((rc = e->d_wg.ensure(std::max<size_t>(1, wg.size()) * 4))) return rc;
-    if ((rc = e->d_split.ensure(std::max<size_t>(1, e->split_list.size()) * 4))) return rc;
     KSP_HIP(hipMemcpy(e->d_act.p, e->act_rec.data(), e->act_rec.size() * 4, hipMemcpyHostToDevice));
     if (!wg.empty()) KSP_HIP(hipMemcpy(e->d_wg.p, wg.data(), wg.size() * 4, hipMemcpyHostToDevice));
-    if (!e->split_list.empty())
-        KSP_HIP(hipMemcpy(e->d_split.p, e->split_list.data(), e->split_list.size() * 4, hipMemcpyHostToDevice));
     e->sched_on = true;
     e->st.n_active_tiles = A;
     return KSP_OK;
@@ -1959,7 +1962,7 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     dim3 block(JW * 64);
     a.blk_max = e->blk_max.as<u32>();
     a.inv = e->smap.as<u32>() + 3 * (((size_t)e->n_sources + 64) & ~(size_t)63);
-    a.sched = nullptr; a.act = nullptr; a.wg0 = 0; a.split0 = 0;
+    a.sched = nullptr; a.act = nullptr; a.wg0 = 0; a.split0 = 0; a.tail_done = nullptr;
     auto launch = [&](bool c16, dim3 grid, const JoinArgs& args) {
         if (e->use_cells) {
             if (e->weighted) { if (c16) hipLaunchKernelGGL((k_join<true, true, true>), grid, block, 0, st, args); else hipLaunchKernelGGL((k_join<true, false, true>), grid, block, 0, st, args); }
@@ -1986,24 +1989,16 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
         a.tailbuf = nullptr;
         const u32 nsplit = spB - spA;
         if (nsplit) {
-            if ((rc = e->tailbuf.ensure((size_t)nsplit * TB * TB * 4))) return rc;
+            if ((rc = e->tailbuf.ensure(((size_t)nsplit * TB * TB + nsplit + 16) * 4))) return rc;
             a.tailbuf = e->tailbuf.as<u32>();
-            KSP_HIP(hipMemsetAsync(a.tailbuf, 0, (size_t)nsplit * TB * TB * 4, st));
+            a.tail_done = a.tailbuf + (size_t)nsplit * TB * TB;
+            KSP_HIP(hipMemsetAsync(a.tailbuf, 0, ((size_t)nsplit * TB * TB + nsplit + 16) * 4, st));
         }
         for (int pass = 0; pass < (e->need32 ? 2 : 1); ++pass)
             for (u64 w = wgA; w < wgB; w += kMaxTilesPerLaunch) {
                 a.wg0 = (u32)w;
                 launch(pass == 0, dim3((u32)std::min<u64>(kMaxTilesPerLaunch, wgB - w)), a);
             }
-        if (nsplit) {
-            JoinArgs te = a;
-            te.sched = e->d_split.as<u32>();
-            for (u32 s0 = 0; s0 < nsplit; s0 += (u32)kMaxTilesPerLaunch) {   // (tail buffer slot = split index - split0)
-                te.split0 = spA + s0;
-                te.tailbuf = a.tailbuf + (size_t)s0 * (TB * TB);
-                hipLaunchKernelGGL(k_tail_emit, dim3(std::min<u32>((u32)kMaxTilesPerLaunch, nsplit - s0)), block, 0, st, te);
-            }
-        }
         KSP_HIP(hipGetLastError());
     }
     for (u64 chunk_begin = tile_begin; !e->sched_on && chunk_begin < tile_end; chunk_begin += kMaxTilesPerLaunch) {
