@@ -111,16 +111,12 @@ __global__ void k_iota(u32* __restrict__ p, u32 n) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = i;
 }
-__global__ void k_rank_first(const u32* __restrict__ rk, u32* __restrict__ first, u64 n) {
-    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n && (e == 0 || rk[e] != rk[e - 1])) first[rk[e]] = (u32)e;
-}
 __device__ inline u32 src_of_tag(u32 t) { return (t >> 8) * TB + (t & 0xFFu); }
 template <class V>
 __global__ void k_label(const u32* __restrict__ rk, const V* __restrict__ vals, const u32* __restrict__ first,
-                        u32* __restrict__ label, u64 n) {
+                        u32* __restrict__ label, const u32 skip, u64 n) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
+    if (e >= n || (rk[e] & skip)) return;
     const u32 s = src_of_tag((u32)vals[e]);
     const u32 f = src_of_tag((u32)vals[first[rk[e]]]);   // entries of a key are in ascending source order
     if (f < label[s]) atomicMin(&label[s], f);
@@ -202,27 +198,75 @@ __global__ void k_mark_first(const u64* __restrict__ keys, int shift, u32* __res
         if (!first) list[i] = (u32)p | DROP;
     }
 }
-// pass 3: one thread per kept position orders its run by the full key (runs are disjoint).
+// pass 3: one wavefront per kept position orders its run by the full key (runs are disjoint).
+// A run (two or three keys, each held by up to a few hundred sources) is ranked through LDS: every
+// entry counts the entries that must precede it (smaller key, or equal key and earlier position:
+// stable, so sources stay ascending inside a key) and is scattered to that place.  Runs longer than
+// FIX_WAVE entries fall back to a serial insertion sort by lane 0.
+constexpr u32 FIX_WAVE = 512;
 template <class V>
-__global__ void k_fix_runs(u64* __restrict__ keys, V* __restrict__ vals, u64 n, int shift,
-                           const u32* __restrict__ list, const u32* __restrict__ count, u32 cap,
-                           u32* __restrict__ overflow) {
+__global__ __launch_bounds__(256) void k_fix_runs(u64* __restrict__ keys, V* __restrict__ vals, u64 n, int shift,
+                                                  const u32* __restrict__ list, const u32* __restrict__ count, u32 cap,
+                                                  u32* __restrict__ overflow) {
+    __shared__ u64 sk[4][FIX_WAVE];
+    __shared__ V sv[4][FIX_WAVE];
     const u32 m = min(*count, cap);
-    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
-        if (list[i] & DROP) continue;
-        const u64 p = list[i];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (u32 i = wave; i < m; i += nwaves) {
+        const u32 li = list[i];
+        if (li & DROP) continue;
+        const u64 p = li;
         const u64 h0 = keys[p] >> shift;
+        // run start: walk back 64 entries at a time
         u64 s = p;
-        while (s > 0 && (keys[s - 1] >> shift) == h0) --s;   // <= MAX_FIX steps (checked by k_mark_first)
+        bool open = true;
+        while (open && p - s < FIX_WAVE) {
+            const bool in = s >= (u64)(64 - lane) && (keys[s - 64 + lane] >> shift) == h0;   // entry s - 64 + lane
+            const unsigned long long mb = __ballot(in);
+            const int back = mb == ~0ull ? 64 : __builtin_clzll(~mb);   // run entries right before s
+            s -= (u64)back;
+            open = back == 64;
+        }
         u64 end = p + 1;
-        while (end < n && (keys[end] >> shift) == h0 && end - s <= MAX_FIX) ++end;
-        if (end - s > MAX_FIX) { *overflow = 1; continue; }
-        // stable insertion sort of the run by full key (keeps ascending source order inside a key)
-        for (u64 a = s + 1; a < end; ++a) {
+        open = true;
+        while (open && end - s <= FIX_WAVE) {
+            const u64 q = end + (u64)lane;
+            const bool in = q < n && (keys[q] >> shift) == h0;
+            const unsigned long long mf = __ballot(in);
+            const int fwd = mf == ~0ull ? 64 : __builtin_ctzll(~mf);
+            end += (u64)fwd;
+            open = fwd == 64;
+        }
+        const u32 len = (u32)(end - s);
+        if (len <= FIX_WAVE) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (u32 j = lane; j < len; j += 64) { sk[wv][j] = keys[s + j]; sv[wv][j] = vals[s + j]; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (u32 j = lane; j < len; j += 64) {
+                const u64 k = sk[wv][j];
+                u32 before = 0;
+                for (u32 t = 0; t < len; ++t) {
+                    const u64 kt = sk[wv][t];
+                    before += (kt < k || (kt == k && t < j)) ? 1u : 0u;
+                }
+                keys[s + before] = k;
+                vals[s + before] = sv[wv][j];
+            }
+            continue;
+        }
+        if (lane != 0) continue;
+        // very long run: serial (rare)
+        u64 s0 = p;
+        while (s0 > 0 && (keys[s0 - 1] >> shift) == h0) --s0;   // <= MAX_FIX steps (checked by k_mark_first)
+        u64 e1 = p + 1;
+        while (e1 < n && (keys[e1] >> shift) == h0 && e1 - s0 <= MAX_FIX) ++e1;
+        if (e1 - s0 > MAX_FIX) { *overflow = 1; continue; }
+        for (u64 a = s0 + 1; a < e1; ++a) {
             const u64 k = keys[a];
             const V v = vals[a];
             u64 j = a;
-            while (j > s && keys[j - 1] > k) { keys[j] = keys[j - 1]; vals[j] = vals[j - 1]; --j; }
+            while (j > s0 && keys[j - 1] > k) { keys[j] = keys[j - 1]; vals[j] = vals[j - 1]; --j; }
             keys[j] = k;
             vals[j] = v;
         }
@@ -247,14 +291,15 @@ struct PruneFn {
 };
 template <class V>
 __global__ void k_prune_scatter(const V* __restrict__ vals, const u64* __restrict__ ps, V* __restrict__ vals2,
-                                u32* __restrict__ rank2, u64* __restrict__ scal, u64 n) {
+                                u32* __restrict__ rank2, u32* __restrict__ first, u64* __restrict__ scal, u64 n) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    const u64 cur = ps[e];
-    const u32 lo = (u32)cur, prev = e ? (u32)ps[e - 1] : 0u;
+    const u64 cur = ps[e], before = e ? ps[e - 1] : 0ull;
+    const u32 lo = (u32)cur, prev = (u32)before;
     if (lo != prev) {   // kept entry
         vals2[lo - 1] = vals[e];
         rank2[lo - 1] = (u32)(cur >> 32) - 1u;
+        if ((cur >> 32) != (before >> 32)) first[(u32)(cur >> 32) - 1u] = lo - 1;   // first kept entry of its key
     }
     if (e == n - 1) {
         scal[6] = lo;                 // kept entries
@@ -1342,7 +1387,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         hipLaunchKernelGGL(k_find_mixed, dim3(grid_for(nw, 4096)), dim3(1024), 0, st, KA, nw, shift, fixlist, d_cnt,
                            fixcap, d_ovf);
         hipLaunchKernelGGL(k_mark_first, dim3(4096), dim3(64), 0, st, KA, shift, fixlist, d_cnt, fixcap, d_ovf);
-        hipLaunchKernelGGL((k_fix_runs<V>), dim3(4096), dim3(64), 0, st, KA, VB, nw, shift, fixlist, d_cnt, fixcap,
+        hipLaunchKernelGGL((k_fix_runs<V>), dim3(2048), dim3(256), 0, st, KA, VB, nw, shift, fixlist, d_cnt, fixcap,
                            d_ovf);
     }
     // singleton pruning + dense ranks of the kept keys (packed counters, one scan):  KA,VB -> R1 (ranks), VA (tags)
@@ -1354,7 +1399,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         if ((rc = e->tmp.ensure(tb))) return rc;
         KSP_HIP(rocprim::inclusive_scan(e->tmp.p, tb, pf, ps, nw, rocprim::plus<u64>(), st));
     }
-    hipLaunchKernelGGL((k_prune_scatter<V>), dim3(grid_for(nw, bs)), dim3(bs), 0, st, VB, ps, VA, rank1, scal, nw);
+    u32* first = (u32*)KA;                 // first kept entry of every rank (KA: the sorted keys are dead once the scan has run)
+    hipLaunchKernelGGL((k_prune_scatter<V>), dim3(grid_for(nw, bs)), dim3(bs), 0, st, VB, ps, VA, rank1, first, scal, nw);
     KSP_HIP(hipMemcpyAsync(e->h_scal + 6, scal + 6, 8, hipMemcpyDeviceToHost, st));
     KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
     m = e->h_scal[6];
@@ -1362,9 +1408,9 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if (m == 0 && phase == 0) return KSP_OK;   // no key is shared by two sources: no pair at all
     if (reorder && m) {
         // label = smallest source id among the holders of a source's shared keys
-        u32* first = (u32*)e->KB.p;        // U entries (the packed prefix sums are dead)
-        hipLaunchKernelGGL(k_rank_first, dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, first, m);
-        hipLaunchKernelGGL((k_label<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, VA, first, label, m);
+        // (sources with hundreds of shared keys: every 8th key says as much about a source's relatives as all)
+        const u32 skip = m / std::max<u32>(1, N) >= 512 ? 7u : 0u;
+        hipLaunchKernelGGL((k_label<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, VA, first, label, skip, m);
     }
     if (phase == 1) return KSP_OK;
     }   // phase != 2
