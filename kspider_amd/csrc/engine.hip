@@ -1083,12 +1083,149 @@ __device__ inline void emit_tile(const JoinArgs& a, const u32 I, const u32 J, co
     }
 }
 
+// ---- diagonal tile of an unweighted block, bit-sliced ------------------------------------------
+// With related sources in one block, a diagonal tile is a dense problem: counts = M^T M for the 0/1
+// membership matrix M (keys x 128 sources).  Instead of one LDS atomic per pair update, the masks of
+// 64 keys are transposed into bit columns (lane-parallel 64 x 64 bit transpose, 6 butterfly steps), a
+// chunk of columns is staged in LDS as col[group][source] (64 keys per 64-bit word), and every thread
+// owns a 4 x 4 patch of source pairs: per group 8 column words, 16 x popcount(a & b).  The 496
+// patches above the diagonal go to threads 0..495; the 192 pairs inside the 32 diagonal patches go
+// one each to threads 0..191.  Results leave as edges straight from registers.
+__device__ inline u64 transpose64_step(u64 x, const int lane, const int j, const u64 m) {
+    const u64 p = __shfl_xor(x, j);
+    return (lane & j) == 0 ? ((x & m) | ((p & m) << j)) : (((p >> j) & m) | (x & (m << j)));
+}
+__device__ inline u64 transpose64(u64 x, const int lane) {   // bit b of lane r  <->  bit r of lane b
+    x = transpose64_step(x, lane, 32, 0x00000000FFFFFFFFull);
+    x = transpose64_step(x, lane, 16, 0x0000FFFF0000FFFFull);
+    x = transpose64_step(x, lane, 8, 0x00FF00FF00FF00FFull);
+    x = transpose64_step(x, lane, 4, 0x0F0F0F0F0F0F0F0Full);
+    x = transpose64_step(x, lane, 2, 0x3333333333333333ull);
+    x = transpose64_step(x, lane, 1, 0x5555555555555555ull);
+    return x;
+}
+__device__ inline void emit_value(const JoinArgs& a, const u32 gi, const u32 gj, const u32 v, const int lane) {
+    const bool nz = v != 0;
+    const unsigned long long mask = __ballot(nz);
+    if (mask == 0) return;
+    unsigned long long wbase = 0;
+    if (lane == 0) wbase = atomicAdd(a.out_count, (unsigned long long)__popcll(mask));
+    wbase = __shfl(wbase, 0);
+    if (nz) {
+        const u64 pos = wbase + __popcll(mask & ((1ull << lane) - 1ull));
+        if (pos < a.cap) {
+            const u32 o1 = a.inv[gi], o2 = a.inv[gj];
+            ksp_edge e;
+            e.source_1 = min(o1, o2);
+            e.source_2 = max(o1, o2);
+            e.shared = v;
+            a.out[pos] = e;
+        }
+    }
+}
+// A share (sub of sp) takes a range of the block's keys; with several shares the partial counts are
+// added into the tile's global buffer `dst` (the caller's last-share logic emits them), otherwise the
+// edges leave straight from the registers.
+template <int SMEM_BYTES>
+__device__ inline void self_tile_popc(const JoinArgs& a, unsigned char* smem, const u32 I, const u32 sub, const u32 sp,
+                                      u32* __restrict__ dst, const int tid, const int lane, const int wv) {
+    static_assert(TB == 128, "bit-sliced diagonal path: two 64-bit words per membership mask");
+    constexpr u32 G = SMEM_BYTES / 1024;   // 64-key groups per chunk (1 KB = 128 columns x 8 B each)
+    u64* col = reinterpret_cast<u64*>(smem);
+    const u32 kall = a.blk_raw[I + 1] - a.blk_raw[I];
+    const u32 kfirst = (u32)(((u64)kall * sub) / sp), klast = (u32)(((u64)kall * (sub + 1)) / sp);
+    const u32 kb0 = a.blk_pos[I] + kfirst, klen = klast - kfirst;   // this share's keys
+    // patches above the diagonal: (ti, tj), ti < tj < 32
+    u32 ti = 0, tj = 1;
+    const bool off = tid < 496;
+    if (off) { tile_decode((u64)tid, 31, ti, tj); tj += 1; }
+    // pairs inside the diagonal patches: patch d = tid / 6, pair q = tid % 6 of its 4 sources
+    const bool dia = tid < 192;
+    const u32 dq = (u32)tid % 6u, dblk = (u32)tid / 6u;
+    const u32 da = dq < 3 ? 0u : dq < 5 ? 1u : 2u;                 // (0,1)(0,2)(0,3)(1,2)(1,3)(2,3)
+    const u32 db = dq < 3 ? dq + 1u : dq < 5 ? dq - 1u : 3u;
+    const u32 s0 = 4u * dblk + da, s1 = 4u * dblk + db;
+    u32 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+    u32 dacc = 0;
+    for (u32 base = 0; base < klen; base += G * 64) {
+        const u32 ng = min(G, (klen - base + 63u) / 64u);
+        // transpose 64 masks into 128 column words; a wave takes groups wv, wv + JW, ...  All posting
+        // words, then all masks of the wave's groups are requested before the first is used (two
+        // rounds of memory latency per chunk, not two per group)
+        constexpr u32 GW = (G + JW - 1) / JW, GB = 3;   // groups per wave and chunk, in batches of GB (register budget)
+        for (u32 q0 = 0; q0 < GW; q0 += GB) {
+            u32 inf[GB];
+            uint4 mk[GB];
+#pragma unroll
+            for (u32 q = 0; q < GB; ++q) {
+                const u32 g = (u32)wv + (q0 + q) * JW, k = base + 64u * g + (u32)lane;
+                inf[q] = (g < ng && k < klen) ? a.info[kb0 + k] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (u32 q = 0; q < GB; ++q) {
+                mk[q] = make_uint4(0, 0, 0, 0);
+                if (inf[q] != 0xFFFFFFFFu && inf[q] >= BIG) mk[q] = a.bigmask[inf[q] & ~BIG];
+            }
+#pragma unroll
+            for (u32 q = 0; q < GB; ++q) {
+                const u32 g = (u32)wv + (q0 + q) * JW;
+                if (g < ng) {
+                    uint4 m = mk[q];
+                    if (inf[q] != 0xFFFFFFFFu && inf[q] < BIG) m = posting_mask(inf[q], a.bigmask);   // inline ids -> mask
+                    const u64 lo = transpose64((u64)m.x | ((u64)m.y << 32), lane);
+                    const u64 hi = transpose64((u64)m.z | ((u64)m.w << 32), lane);
+                    col[g * 128u + (u32)lane] = lo;
+                    col[g * 128u + 64u + (u32)lane] = hi;
+                }
+            }
+        }
+        __syncthreads();
+        if (off) {
+            for (u32 g = 0; g < ng; ++g) {
+                const ulonglong2* r = reinterpret_cast<const ulonglong2*>(col + g * 128u + 4u * ti);
+                const ulonglong2* c = reinterpret_cast<const ulonglong2*>(col + g * 128u + 4u * tj);
+                const ulonglong2 r01 = r[0], r23 = r[1], c01 = c[0], c23 = c[1];
+                const u64 rr[4] = {r01.x, r01.y, r23.x, r23.y};
+                const u64 cc[4] = {c01.x, c01.y, c23.x, c23.y};
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; ++y) acc[4 * x + y] += (u32)__popcll(rr[x] & cc[y]);
+            }
+        }
+        if (dia) {
+            for (u32 g = 0; g < ng; ++g) dacc += (u32)__popcll(col[g * 128u + s0] & col[g * 128u + s1]);
+        }
+        __syncthreads();
+    }
+    if (dst) {   // one of several shares: partial counts into the tile's buffer
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y)
+                if (off && acc[4 * x + y]) atomicAdd(&dst[(4u * ti + (u32)x) * TB + 4u * tj + (u32)y], acc[4 * x + y]);
+        if (dia && dacc) atomicAdd(&dst[s0 * TB + s1], dacc);
+        return;
+    }
+    const u32 g0 = I * TB;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) emit_value(a, g0 + 4u * ti + (u32)x, g0 + 4u * tj + (u32)y, off ? acc[4 * x + y] : 0u, lane);
+    emit_value(a, g0 + s0, g0 + s1, dia ? dacc : 0u, lane);
+}
+
 template <bool W, bool C16, bool CELLS>
 __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
     // pair counters (32 KB packed 16-bit / 64 KB 32-bit) + 8 x (1.3 KB B window + 0.5 KB match
     // queue): three (C16) or two workgroups per CU
-    __shared__ u32 S[C16 ? TB * TB / 2 : TB * TB];
-    __shared__ WaveLds wlds[JW];
+    constexpr int S_BYTES = (C16 ? TB * TB / 2 : TB * TB) * 4;
+    constexpr int SMEM_BYTES = S_BYTES + (int)sizeof(WaveLds) * JW;
+    __shared__ __align__(16) unsigned char smem[SMEM_BYTES];   // (the bit-sliced diagonal path uses all of it as one buffer)
+    u32* S = reinterpret_cast<u32*>(smem);
+    WaveLds* wlds = reinterpret_cast<WaveLds*>(smem + S_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps index arithmetic and loads scalar
@@ -1119,6 +1256,13 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
     // 16-bit counters are exact iff one of the two blocks has no source with >= 2^16 k-mers
     if ((min(a.blk_max[I], a.blk_max[J]) < 65536u) != C16) return;
 
+    const bool popc = I == J && !W;
+    if (popc) {
+        // unweighted diagonal tile: bit-sliced M^T M from registers (no counter tile, no LDS atomics)
+        u32* dst = tail_id != 0xFFFFFFFFu ? a.tailbuf + (size_t)tail_id * (TB * TB) : nullptr;
+        self_tile_popc<SMEM_BYTES>(a, smem, I, sub, sp, dst, tid, lane, wv);
+        if (!dst) return;
+    } else {
     for (int i = tid; i < (C16 ? TB * TB / 2 : TB * TB); i += JW * 64) S[i] = 0;
     __syncthreads();
 
@@ -1161,12 +1305,13 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
     } else {
         join_windows<W, C16>(a, S, wlds[wv], I, J, wv, lane, sub, sp);
     }
+    }   // !popc
     __syncthreads();
 
     if (tail_id != 0xFFFFFFFFu) {
         // tail share: add the partial counters into the tile's global buffer (k_tail_emit compacts it)
         u32* dst = a.tailbuf + (size_t)tail_id * (TB * TB);
-        for (int base = 0; base < TB * TB; base += JW * 64) {
+        for (int base = 0; !popc && base < TB * TB; base += JW * 64) {
             const int idx = base + tid;
             const u32 v = C16 ? ((S[idx >> 1] >> ((idx & 1) * 16)) & 0xFFFFu) : S[idx];
             if (v) atomicAdd(&dst[idx], v);
@@ -1587,15 +1732,18 @@ static int build_schedule(ksp_engine* e) {
     if ((rc = query_slots(e))) return rc;
     auto words_of = [&](u32 b) { return (u64)(e->h_blk_off[b + 1] - e->h_blk_off[b]); };
     auto cost_of = [&](u32 I, u32 J) -> u64 {
-        return I == J ? dw[I] / 2 + 10 * words_of(I) + 2000 : 8 * (words_of(I) + words_of(J)) + 2000;
+        if (I == J && !e->weighted) return 40 * words_of(I) + 20000;   // bit-sliced: 16 popcounts x 528 patches per 64 keys
+        return I == J ? dw[I] / 2 + 10 * words_of(I) + 20000 : 8 * (words_of(I) + words_of(J)) + 20000;
     };
     // pass 1: active tiles and total cost
     u64 total = 0;
     e->act_tid.reserve((size_t)active);
+    const char* only = std::getenv("KSP_DEBUG_ONLY");   // timing experiments: "diag" / "off" (results are incomplete)
+    const bool skip_diag = only && std::string(only) == "off", skip_off = only && std::string(only) == "diag";
     for (u32 I = 0; I < nb; ++I) {
         const u64 row = tile_row_start(I, nb);
-        if (dw[I]) { e->act_tid.push_back(row); total += cost_of(I, I); }
-        for (u64 t = row + 1; t < row + (nb - I);) {
+        if (dw[I] && !skip_diag) { e->act_tid.push_back(row); total += cost_of(I, I); }
+        for (u64 t = row + 1; !skip_off && t < row + (nb - I);) {
             const u32 wrd = bits[t >> 5] >> (t & 31);
             if (!wrd) { t = (t | 31) + 1; continue; }
             const u64 tt = t + (u64)__builtin_ctz(wrd);
@@ -1607,7 +1755,7 @@ static int build_schedule(ksp_engine* e) {
     }
     const size_t A = e->act_tid.size();
     // (a sharded job joins 1/nparts of the list per GPU: size the shares for that)
-    const u64 target = std::max<u64>(total / ((u64)e->slots * 3 * std::max<u32>(1, e->nparts)) + 1, 20000);
+    const u64 target = std::max<u64>(total / ((u64)e->slots * 3 * std::max<u32>(1, e->nparts)) + 1, 100000);
     // pass 2: shares
     std::vector<u32> wg;
     wg.reserve(A + (size_t)e->slots * 4);
