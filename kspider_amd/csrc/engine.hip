@@ -1217,8 +1217,189 @@ __device__ inline void self_tile_popc(const JoinArgs& a, unsigned char* smem, co
     emit_value(a, g0 + s0, g0 + s1, dia ? dacc : 0u, lane);
 }
 
+// ---- off-diagonal tile of unweighted blocks: collect the matches, accumulate them bit-sliced ------
+// Expanding one match costs cA x cB counter updates — quadratic in the cluster size once related
+// sources share a block.  Instead the workgroup works in rounds: every wave searches one step (a
+// 256-key chunk of A against a 256-key window of B) and appends its matches (two list positions) to
+// an LDS buffer; then, 512 matches at a time, the waves fetch the two membership masks of their
+// matches, transpose them into bit columns (colA[g][source of I], colB[g][source of J], 64 matches
+// per word) and every thread adds popcount(a & b) for its two 4 x 4 patches of the 128 x 128 tile.
+// The cost per match no longer depends on the size of the postings.
+constexpr u32 MCAP = 2048;    // matches per round: 8 waves x (at most 256 per step)
+constexpr u32 MSUB = 512;     // matches per accumulation batch: 8 groups of 64, one per wave
+struct CollectLds {
+    uint2 match[MCAP];            // (position in list I, position in list J)
+    u64 col[2][MSUB / 64][TB];    // [A / B][group][source]
+};
+// C16: the tile's counts stay below 2^16 (one block has no source with >= 2^16 k-mers), so two
+// 16-bit counters share a register: 16 instead of 32 accumulator registers per thread.
+template <int S_BYTES, bool C16>
+__device__ inline void join_cells_collect(const JoinArgs& a, unsigned char* smem, WaveLds& wl, const u32 I, const u32 J,
+                                          const u32 sub, const u32 sp, u32* __restrict__ dst, const int tid, const int lane,
+                                          const int wv) {
+    static_assert(sizeof(CollectLds) <= (size_t)S_BYTES, "collect buffers must fit the counter tile's LDS");
+    static_assert(TB == 128 && JW == 8, "bit-sliced accumulation: 128 x 128 tile, 8 waves");
+    CollectLds& cl = *reinterpret_cast<CollectLds*>(smem);
+    __shared__ u32 s_n, s_more;
+    const u32* cI = a.cidx + (size_t)I * (a.ncell + 1);
+    const u32* cJ = a.cidx + (size_t)J * (a.ncell + 1);
+    const u32 kI = a.blk_raw[I + 1] - a.blk_raw[I], kJ = a.blk_raw[J + 1] - a.blk_raw[J];
+    const u32 kmax = max(max(kI, kJ), 1u);
+    u32 m = (u32)(((u64)CELL_TARGET * a.ncell) / kmax);
+    m = __builtin_amdgcn_readfirstlane(max(1u, min(m, a.ncell)));
+    const u32 ncoarse = (a.ncell + m - 1) / m;
+    const u32 wbeg = (u32)(((u64)ncoarse * sub) / sp), wend = (u32)(((u64)ncoarse * (sub + 1)) / sp);
+    // this wave's cells: wbeg + wv, + JW, ...; inside a cell the steps (chunk x window) in order
+    u32 c = wbeg + (u32)wv;
+    u32 a0 = 0, a1 = 0, b0 = 0, b1 = 0, ca = 0, cb = 0;   // current cell / step
+    bool have = false;
+    auto open_cell = [&]() {
+        have = false;
+        while (c < wend) {
+            const u32 f0 = c * m, f1 = min(a.ncell, f0 + m);
+            a0 = __builtin_amdgcn_readfirstlane(cI[f0]); a1 = __builtin_amdgcn_readfirstlane(cI[f1]);
+            b0 = __builtin_amdgcn_readfirstlane(cJ[f0]); b1 = __builtin_amdgcn_readfirstlane(cJ[f1]);
+            if (a1 > a0 && b1 > b0) { ca = a0 & ~3u; cb = b0 & ~3u; have = true; return; }
+            c += JW;
+        }
+    };
+    open_cell();
+    // the two 4 x 4 patches of this thread: rows 4 pi .. (block I), columns 4 pj .. (block J)
+    const u32 pi0 = (u32)tid >> 5, pi1 = pi0 + 16u, pj = (u32)tid & 31u;
+    constexpr int NA = C16 ? 8 : 16;   // C16: acc[k] = pairs (x, 2k) and (x, 2k + 1) ... see below
+    u32 acc0[NA], acc1[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { acc0[i] = 0; acc1[i] = 0; }
+    u32 s0 = 0, s1 = 0, s2 = 0;
+    while (true) {
+        __syncthreads();   // (everyone has read the previous round's s_n / s_more)
+        if (tid == 0) { s_n = 0; s_more = 0; }
+        __syncthreads();
+        if (have) {
+            // one step: chunk [ca, ca + 256) of the cell's A keys against window [cb, cb + 256) of its B keys
+            const uint4 A = load_a(a, ca, a0, a1, lane);
+            const uint4 B = load_b(a, cb, b1, lane);
+            Window& wn = wl.win;
+            u32* l2w = reinterpret_cast<u32*>(wn.l2);
+            u32* l1w = reinterpret_cast<u32*>(wn.l1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            wn.leaf[lane] = B;
+            l2w[lane] = B.w;
+            if ((lane & 3) == 3) l1w[lane >> 2] = B.w;
+            s0 = __builtin_amdgcn_readlane(B.w, 15);
+            s1 = __builtin_amdgcn_readlane(B.w, 31);
+            s2 = __builtin_amdgcn_readlane(B.w, 47);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            bool h0, h1, h2, h3;
+            const u32 p0 = window_find(wn, s0, s1, s2, A.x, h0);
+            const u32 p1 = window_find(wn, s0, s1, s2, A.y, h1);
+            const u32 p2 = window_find(wn, s0, s1, s2, A.z, h2);
+            const u32 p3 = window_find(wn, s0, s1, s2, A.w, h3);
+            const unsigned long long m0 = __ballot(h0), m1 = __ballot(h1), m2 = __ballot(h2), m3 = __ballot(h3);
+            const u32 n0 = (u32)__popcll(m0), n1 = (u32)__popcll(m1), n2 = (u32)__popcll(m2), n3 = (u32)__popcll(m3);
+            const u32 cnt = n0 + n1 + n2 + n3;
+            u32 base = 0;
+            if (lane == 0 && cnt) base = atomicAdd(&s_n, cnt);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const u32 qa = ca + 4u * (u32)lane;
+            if (h0) cl.match[base + __builtin_amdgcn_mbcnt_hi((u32)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m0, 0))] = make_uint2(qa, cb + p0);
+            base += n0;
+            if (h1) cl.match[base + __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, 0))] = make_uint2(qa + 1, cb + p1);
+            base += n1;
+            if (h2) cl.match[base + __builtin_amdgcn_mbcnt_hi((u32)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m2, 0))] = make_uint2(qa + 2, cb + p2);
+            base += n2;
+            if (h3) cl.match[base + __builtin_amdgcn_mbcnt_hi((u32)(m3 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m3, 0))] = make_uint2(qa + 3, cb + p3);
+            // next step of this wave: next A chunk of the window, next window, next cell
+            ca += WIN;
+            if (ca >= a1) {
+                ca = a0 & ~3u;
+                cb += WIN;
+                if (cb >= b1) { c += JW; open_cell(); }
+            }
+            if (have && lane == 0) s_more = 1;
+        }
+        __syncthreads();
+        const u32 n = s_n;
+        const bool more = s_more != 0;
+        for (u32 mb = 0; mb < n; mb += MSUB) {
+            // masks of 64 matches per wave -> bit columns
+            const u32 mi = mb + 64u * (u32)wv + (u32)lane;
+            uint4 ma = make_uint4(0, 0, 0, 0), mbm = ma;
+            if (mi < n) {
+                const uint2 q = cl.match[mi];
+                const u32 ia = a.info[q.x], ib = a.info[q.y];
+                ma = posting_mask(ia, a.bigmask);
+                mbm = posting_mask(ib, a.bigmask);
+            }
+            if (mb + 64u * (u32)wv < n) {   // wave-uniform; one transpose at a time keeps the register count down
+                cl.col[0][wv][lane] = transpose64((u64)ma.x | ((u64)ma.y << 32), lane);
+                __builtin_amdgcn_sched_barrier(0);
+                cl.col[0][wv][64 + lane] = transpose64((u64)ma.z | ((u64)ma.w << 32), lane);
+                __builtin_amdgcn_sched_barrier(0);
+                cl.col[1][wv][lane] = transpose64((u64)mbm.x | ((u64)mbm.y << 32), lane);
+                __builtin_amdgcn_sched_barrier(0);
+                cl.col[1][wv][64 + lane] = transpose64((u64)mbm.z | ((u64)mbm.w << 32), lane);
+            }
+            __syncthreads();
+            const u32 ng = min((u32)(MSUB / 64), (n - mb + 63u) / 64u);
+#pragma unroll 1
+            for (u32 g = 0; g < ng; ++g) {
+                const ulonglong2* cc = reinterpret_cast<const ulonglong2*>(&cl.col[1][g][4u * pj]);
+                const ulonglong2 c01 = cc[0], c23 = cc[1];
+                const u64 cw[4] = {c01.x, c01.y, c23.x, c23.y};
+                {
+                    const ulonglong2* r0 = reinterpret_cast<const ulonglong2*>(&cl.col[0][g][4u * pi0]);
+                    const ulonglong2 x01 = r0[0], x23 = r0[1];
+                    const u64 rw[4] = {x01.x, x01.y, x23.x, x23.y};
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int y = 0; y < 4; y += 2) {
+                            const u32 v0 = (u32)__popcll(rw[x] & cw[y]), v1 = (u32)__popcll(rw[x] & cw[y + 1]);
+                            if (C16) acc0[2 * x + y / 2] += v0 | (v1 << 16);
+                            else { acc0[4 * x + y] += v0; acc0[4 * x + y + 1] += v1; }
+                        }
+                }
+                {
+                    const ulonglong2* r1 = reinterpret_cast<const ulonglong2*>(&cl.col[0][g][4u * pi1]);
+                    const ulonglong2 y01 = r1[0], y23 = r1[1];
+                    const u64 rw[4] = {y01.x, y01.y, y23.x, y23.y};
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int y = 0; y < 4; y += 2) {
+                            const u32 v0 = (u32)__popcll(rw[x] & cw[y]), v1 = (u32)__popcll(rw[x] & cw[y + 1]);
+                            if (C16) acc1[2 * x + y / 2] += v0 | (v1 << 16);
+                            else { acc1[4 * x + y] += v0; acc1[4 * x + y + 1] += v1; }
+                        }
+                }
+            }
+            __syncthreads();
+        }
+        if (!more) break;
+    }
+    // results: partial counts into the tile's buffer (one of several shares) or straight to edges
+    const u32 gi = I * TB, gj = J * TB;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const u32 r0 = 4u * pi0 + (u32)x, r1 = 4u * pi1 + (u32)x, cc = 4u * pj + (u32)y;
+            const u32 v0 = C16 ? (acc0[2 * x + y / 2] >> (16 * (y & 1))) & 0xFFFFu : acc0[C16 ? 0 : 4 * x + y];
+            const u32 v1 = C16 ? (acc1[2 * x + y / 2] >> (16 * (y & 1))) & 0xFFFFu : acc1[C16 ? 0 : 4 * x + y];
+            if (dst) {
+                if (v0) atomicAdd(&dst[r0 * TB + cc], v0);
+                if (v1) atomicAdd(&dst[r1 * TB + cc], v1);
+            } else {
+                emit_value(a, gi + r0, gj + cc, v0, lane);
+                emit_value(a, gi + r1, gj + cc, v1, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (keeps hipcc from hoisting all 64 id look-ups: registers)
+        }
+}
+
 template <bool W, bool C16, bool CELLS>
-__global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
+__global__ __launch_bounds__(JW * 64, 6) void k_join(JoinArgs a) {   // (6 waves per SIMD = three workgroups per CU: caps the unweighted variant at 80 VGPRs)
     // pair counters (32 KB packed 16-bit / 64 KB 32-bit) + 8 x (1.3 KB B window + 0.5 KB match
     // queue): three (C16) or two workgroups per CU
     constexpr int S_BYTES = (C16 ? TB * TB / 2 : TB * TB) * 4;
@@ -1256,11 +1437,12 @@ __global__ __launch_bounds__(JW * 64) void k_join(JoinArgs a) {
     // 16-bit counters are exact iff one of the two blocks has no source with >= 2^16 k-mers
     if ((min(a.blk_max[I], a.blk_max[J]) < 65536u) != C16) return;
 
-    const bool popc = I == J && !W;
+    const bool popc = !W && (I == J || CELLS);
     if (popc) {
-        // unweighted diagonal tile: bit-sliced M^T M from registers (no counter tile, no LDS atomics)
+        // unweighted tiles: bit-sliced accumulation in registers (no counter tile, no LDS atomics)
         u32* dst = tail_id != 0xFFFFFFFFu ? a.tailbuf + (size_t)tail_id * (TB * TB) : nullptr;
-        self_tile_popc<SMEM_BYTES>(a, smem, I, sub, sp, dst, tid, lane, wv);
+        if (I == J) self_tile_popc<SMEM_BYTES>(a, smem, I, sub, sp, dst, tid, lane, wv);
+        else join_cells_collect<S_BYTES, C16>(a, smem, wlds[wv], I, J, sub, sp, dst, tid, lane, wv);
         if (!dst) return;
     } else {
     for (int i = tid; i < (C16 ? TB * TB / 2 : TB * TB); i += JW * 64) S[i] = 0;
@@ -1755,7 +1937,10 @@ static int build_schedule(ksp_engine* e) {
     }
     const size_t A = e->act_tid.size();
     // (a sharded job joins 1/nparts of the list per GPU: size the shares for that)
-    const u64 target = std::max<u64>(total / ((u64)e->slots * 3 * std::max<u32>(1, e->nparts)) + 1, 100000);
+    u64 quarter_shares = 2;   // shares per workgroup slot of the chip, in quarters: half a wave of workgroups measured best
+                              // on C2 (0.46 ms vs 0.55 at one per slot, 0.84 at three); KSP_DEBUG_SHARES: experiments
+    if (const char* sf = std::getenv("KSP_DEBUG_SHARES")) quarter_shares = std::max(1, std::atoi(sf));
+    const u64 target = std::max<u64>(4 * total / ((u64)e->slots * quarter_shares * std::max<u32>(1, e->nparts)) + 1, 100000);
     // pass 2: shares
     std::vector<u32> wg;
     wg.reserve(A + (size_t)e->slots * 4);

@@ -92,3 +92,30 @@ def test_work_list_and_balanced_cuts(c2):
         assert active == st["n_active_tiles"]
         parts = np.sort(np.concatenate(parts), order=["source_1", "source_2"])
         assert (parts == full).all()
+
+
+@pytest.mark.parametrize("cfg,n,env", [("C4", 6000, {}), ("C4", 6000, {"KSP_NO_SCHED": "1"}),
+                                       ("C5", 60000, {}), ("C3", 5000, {"KSP_REORDER": "0"})])
+def test_other_shapes_checksum_and_samples(cfg, n, env, monkeypatch):
+    """Shapes the small oracle cases do not reach (lognormal sizes with 32-bit-counter tiles, many tiny
+    sketches, tiles whose search rounds find nothing): sum of all counts == sum_k C(holders_k, 2) from an
+    independent host-side inverted index, plus sampled pairs by direct intersection."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sk = synth.generate(cfg, n_sources=n)
+    dk = engine.DeviceBuffer.from_numpy(sk.keys)
+    e = engine.Engine(0)
+    e.build_blocks(dk.ptr.value, sk.offsets)
+    T = e.num_tiles
+    cap = int(e.edge_bound(0, T)) + 1
+    de = engine.DeviceBuffer(cap * 16)
+    ev = _join(e, de, cap, 0, T)
+    _, counts = np.unique(sk.keys, return_counts=True)
+    assert int(ev["shared"].sum()) == int((counts.astype(np.int64) * (counts - 1) // 2).sum())
+    assert (ev["source_1"] < ev["source_2"]).all() and int(ev["source_2"].max()) < sk.n_sources
+    key = ev["source_1"].astype(np.int64) * sk.n_sources + ev["source_2"]
+    assert (np.diff(key) > 0).all()
+    rng = np.random.default_rng(5)
+    for i in rng.choice(len(ev), size=min(300, len(ev)), replace=False):
+        a, b, s = int(ev["source_1"][i]), int(ev["source_2"][i]), int(ev["shared"][i])
+        assert np.intersect1d(sk.run(a), sk.run(b), assume_unique=True).size == s
