@@ -53,6 +53,10 @@ typedef struct ksp_stats {
     uint64_t n_active_tiles;    /* tiles with something to count (block pairs sharing a key, diagonal
                                    tiles of blocks with a multi-source key); = n_tiles in dense mode */
     uint64_t last_active_tiles; /* ... among the tiles of the last ksp_engine_join                   */
+    uint64_t sort_entries;      /* entries of the global radix sort of the last build (rocPRIM onesweep:
+                                   8-byte key + 4/8-byte tag read and written once per 8-bit pass)      */
+    float ms_sort;              /* its HIP-event time (all passes + histogram)                        */
+    int sort_bits;              /* key bits it sorted on                                              */
 } ksp_stats;
 
 const char* ksp_last_error(void);

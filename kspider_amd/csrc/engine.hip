@@ -1577,8 +1577,10 @@ struct ksp_engine {
     ksp::Buf tbits, dwork, d_act, d_wg;
     unsigned long long* h_count = nullptr;   // pinned
     u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
+    u64 sort_entries = 0;                    // entries / key bits of the last global radix sort (stats)
+    int sort_bits = 0;
     u64 h_scal_words = 0, h_scal_keys = 0;   // list words / distinct shared keys of the lists being finished
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // build, join, first radix sort
     ksp_stats st{};
 };
 
@@ -1704,7 +1706,11 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     tb = 0;
     KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, KA, tags_in, VB, nw, shift, kbits, st));
     if ((rc = e->tmp.ensure(tb))) return rc;
+    KSP_HIP(hipEventRecord(e->ev[4], st));
     KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, keys_in, KA, tags_in, VB, nw, shift, kbits, st));
+    KSP_HIP(hipEventRecord(e->ev[5], st));
+    e->sort_entries = nw;
+    e->sort_bits = kbits - shift;
     if (shift > 0) {
         // KB is free until the rank scan: use it for the work list of mixed runs
         u32* fixlist = (u32*)e->KB.p;
@@ -1862,7 +1868,7 @@ int ksp_engine_create(int device, ksp_engine** out) {
     e->device = device;
     KSP_HIP(hipHostMalloc((void**)&e->h_count, 64));
     KSP_HIP(hipHostMalloc((void**)&e->h_scal, 128));
-    for (int i = 0; i < 4; ++i) KSP_HIP(hipEventCreate(&e->ev[i]));
+    for (int i = 0; i < 6; ++i) KSP_HIP(hipEventCreate(&e->ev[i]));
     *out = e;
     return KSP_OK;
 }
@@ -1876,7 +1882,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
-    for (int i = 0; i < 4; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    for (int i = 0; i < 6; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     delete e;
 }
 
@@ -2013,6 +2019,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     e->st = ksp_stats{};
     e->st.n_sources = n_sources;
     e->st.n_entries = n;
+    e->sort_entries = 0;
     e->st.n_blocks = e->nb;
     e->st.n_tiles = (u64)e->nb * (e->nb + 1) / 2;
     e->st.weighted = e->weighted;
@@ -2061,6 +2068,10 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     KSP_HIP(hipStreamSynchronize(st));
     KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
     e->st.key_bits = e->key_bits;
+    e->st.ms_sort = 0;
+    e->st.sort_entries = e->sort_entries;
+    e->st.sort_bits = e->sort_bits;
+    if (e->sort_entries) KSP_HIP(hipEventElapsedTime(&e->st.ms_sort, e->ev[4], e->ev[5]));
     return KSP_OK;
 }
 
