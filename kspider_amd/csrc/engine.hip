@@ -358,6 +358,14 @@ __global__ void k_blk_pos(const u32* __restrict__ blk_raw, u32* __restrict__ blk
     }
 }
 
+// tail pads of every block list (+inf ranks): from the end of list b to the start of list b + 1, and
+// 4 windows of slack behind the last list
+__global__ void k_pad(const u32* __restrict__ blk_raw, const u32* __restrict__ blk_pos, u32* __restrict__ brk, u32 nb, u32 padv) {
+    const u32 b = blockIdx.x;
+    const u32 lo = b < nb ? blk_pos[b] + (blk_raw[b + 1] - blk_raw[b]) : blk_pos[nb];
+    const u32 hi = b < nb ? blk_pos[b + 1] : blk_pos[nb] + 4u * WIN;
+    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) brk[i] = padv;
+}
 __global__ void k_fill(u32* __restrict__ p, u32 v, u64 n) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1779,18 +1787,23 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     hipLaunchKernelGGL(k_ktot, dim3(1), dim3(64), 0, st, flag, didx, estart, scal, m);
     hipLaunchKernelGGL((k_blk_raw<V>), dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, T, didx, scal, blk_raw, nb, m);
     hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, blk_raw, blk_pos, scal, nb);
-    hipLaunchKernelGGL(k_fill, dim3(grid_for(lmax, bs)), dim3(bs), 0, st, e->bkeys.as<u32>(), PAD, lmax);
+    hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
     hipLaunchKernelGGL((k_emit_keys<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rk2, T, flag, didx, blk_raw,
                        blk_pos, e->bkeys.as<u32>(), estart, m);
+    // the number of distinct (block, key) groups sizes the posting passes (after the source reordering it is
+    // an order of magnitude below the entry count: one 8-byte read-back pays for itself)
+    KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 8, hipMemcpyDeviceToHost, st));
+    KSP_HIP(hipStreamSynchronize(st));
+    const u64 K = std::max<u64>(1, e->h_scal[1]);
     u32* mmsz = flag;                      // flags are dead now
     u32* mmoff = (u32*)KA;                 // rk2 is dead after k_emit_keys
-    hipLaunchKernelGGL(k_bigflag, dim3(grid_for(m, bs)), dim3(bs), 0, st, estart, scal, mmsz, m);
+    hipLaunchKernelGGL(k_bigflag, dim3(grid_for(K, bs)), dim3(bs), 0, st, estart, scal, mmsz, K);
     tb = 0;
-    KSP_HIP(rocprim::exclusive_scan(nullptr, tb, mmsz, mmoff, (u32)0, m, rocprim::plus<u32>(), st));
+    KSP_HIP(rocprim::exclusive_scan(nullptr, tb, mmsz, mmoff, (u32)0, K, rocprim::plus<u32>(), st));
     if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, mmsz, mmoff, (u32)0, m, rocprim::plus<u32>(), st));
+    KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, mmsz, mmoff, (u32)0, K, rocprim::plus<u32>(), st));
     hipLaunchKernelGGL(k_nbig, dim3(1), dim3(64), 0, st, mmsz, mmoff, scal);
-    hipLaunchKernelGGL((k_emit_info<V, W>), dim3(grid_for(m, bs)), dim3(bs), 0, st, estart, mmoff, scal, T,
+    hipLaunchKernelGGL((k_emit_info<V, W>), dim3(grid_for(K, bs)), dim3(bs), 0, st, estart, mmoff, scal, T,
                        blk_raw, blk_pos, e->info.as<u32>(), e->mm.as<uint4>(), W ? e->bw.as<u32>() : nullptr);
     // rank-range partition of every block list
     hipLaunchKernelGGL(k_cidx, dim3(grid_for((u64)nb * (e->ncell + 1), bs)), dim3(bs), 0, st, e->bkeys.as<u32>(),
@@ -2221,7 +2234,7 @@ int ksp_engine_assemble(ksp_engine* e, uint32_t nparts, const uint64_t* h_sizes 
     u64* scal = e->scalars.as<u64>();
     hipLaunchKernelGGL(k_asm_counts, dim3(1), dim3(64), 0, st, d_blk_raw_all, nb + 1, nparts, nb, e->blk_raw.as<u32>());
     hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), scal, nb);
-    hipLaunchKernelGGL(k_fill, dim3(grid_for(lmax, 256)), dim3(256), 0, st, e->bkeys.as<u32>(), PAD, lmax);
+    hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), e->bkeys.as<u32>(), nb, PAD);
     const u32* roff = e->asm_small.as<u32>();
     if (e->weighted)
         hipLaunchKernelGGL((k_asm_copy<true>), dim3(nb, nparts), dim3(256), 0, st, d_brk_all, d_info_all, d_bw_all,
