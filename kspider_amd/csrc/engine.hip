@@ -1579,10 +1579,14 @@ struct ksp_engine {
     u32 slots = 0;                // workgroups of k_join the chip holds at once (occupancy x CUs)
     // work list of the join (built by finish_build; empty -> dense mode: every tile is visited)
     bool sched_on = false;
+    hipStream_t sched_stream = nullptr;   // stream of the build that produced the work list (its uploads are ordered on it)
     bool have_bits = false;       // tbits / dwork hold this build's tile bitmap and diagonal work
     std::vector<u64> act_tid;     // active tiles (row-major tile ids, ascending)
     std::vector<u32> act_rec;     // per active tile: I, J, first workgroup, split index (+ one sentinel record)
     ksp::Buf tbits, dwork, d_act, d_wg;
+    unsigned char* h_stage = nullptr;   // pinned: diagonal work + overflow flag, then the tile bitmap
+    size_t h_stage_bytes = 0;
+    std::vector<u32> wg_host;           // share -> active tile (kept alive for the asynchronous upload)
     unsigned long long* h_count = nullptr;   // pinned
     u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
     u64 sort_entries = 0;                    // entries / key bits of the last global radix sort (stats)
@@ -1816,6 +1820,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
 // key and the pair-update count of every diagonal tile; finish_build turns them into the work list.
 static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     e->have_bits = false;
+    e->sched_stream = st;
     const u32 nb = e->nb;
     const u64 K = e->h_scal_words;   // list words (set by the caller)
     const u64 U = e->h_scal_keys;
@@ -1827,13 +1832,13 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     int rc;
     const size_t bit_words = (size_t)(((T + 63) / 64) * 2 + 2);
     if ((rc = e->tbits.ensure(bit_words * 4 + T + 64))) return rc;   // packed bitmap, then one flag byte per tile
-    if ((rc = e->dwork.ensure(((size_t)nb + 1) * 8))) return rc;
+    if ((rc = e->dwork.ensure(((size_t)nb + 2) * 8))) return rc;
     if ((rc = e->KA.ensure((K + 4) * 8))) return rc;
     if ((rc = e->KB.ensure((K + 4) * 8))) return rc;
     u32 *pr = (u32*)e->KA.p, *pb = pr + (K + 4), *pr2 = (u32*)e->KB.p, *pb2 = pr2 + (K + 4);
     unsigned char* flags = (unsigned char*)e->tbits.p + bit_words * 4;
     KSP_HIP(hipMemsetAsync(e->tbits.p, 0, bit_words * 4 + T + 64, st));
-    KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 1) * 8, st));
+    KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
     const u32 shares = (u32)std::min<u64>(64, std::max<u64>(1, 2048 / nb));
     hipLaunchKernelGGL(k_list_pairs, dim3(nb, shares), dim3(256), 0, st, e->bkeys.as<u32>(), e->info.as<u32>(),
                        e->mm.as<uint4>(), e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), pr, pb,
@@ -1846,6 +1851,16 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, pr, pr2, pb, pb2, (size_t)K, 0, rbits, st));
     hipLaunchKernelGGL(k_tile_flags, dim3(grid_for(K, 256)), dim3(256), 0, st, pr2, pb2, K, nb, flags);
     hipLaunchKernelGGL(k_pack_flags, dim3(grid_for(T, 256)), dim3(256), 0, st, flags, T, e->tbits.as<u32>());
+    // results to pinned host memory in stream order: the caller's end-of-build synchronisation covers them
+    const size_t stage_bytes = bit_words * 4 + ((size_t)nb + 2) * 8;
+    if (e->h_stage_bytes < stage_bytes) {
+        if (e->h_stage) (void)hipHostFree(e->h_stage);
+        e->h_stage = nullptr; e->h_stage_bytes = 0;
+        KSP_HIP(hipHostMalloc((void**)&e->h_stage, stage_bytes + stage_bytes / 4 + 4096));
+        e->h_stage_bytes = stage_bytes + stage_bytes / 4 + 4096;
+    }
+    KSP_HIP(hipMemcpyAsync(e->h_stage, e->dwork.p, ((size_t)nb + 2) * 8, hipMemcpyDeviceToHost, st));
+    KSP_HIP(hipMemcpyAsync(e->h_stage + ((size_t)nb + 2) * 8, e->tbits.p, bit_words * 4, hipMemcpyDeviceToHost, st));
     KSP_HIP(hipGetLastError());
     e->have_bits = true;
     return KSP_OK;
@@ -1895,6 +1910,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
+    if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (int i = 0; i < 6; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     delete e;
 }
@@ -1921,10 +1937,9 @@ static int build_schedule(ksp_engine* e) {
     const u32 nb = e->nb;
     const u64 T = (u64)nb * (nb + 1) / 2;
     const size_t words = (size_t)(((T + 63) / 64) * 2);
-    std::vector<u32> bits(words + 2);
-    std::vector<unsigned long long> dw((size_t)nb + 1);
-    KSP_HIP(hipMemcpy(bits.data(), e->tbits.p, words * 4, hipMemcpyDeviceToHost));
-    KSP_HIP(hipMemcpy(dw.data(), e->dwork.p, ((size_t)nb + 1) * 8, hipMemcpyDeviceToHost));
+    // (copied to pinned memory by launch_sched_kernels; the build has been synchronised since)
+    const unsigned long long* dw = reinterpret_cast<const unsigned long long*>(e->h_stage);
+    const u32* bits = reinterpret_cast<const u32*>(e->h_stage + ((size_t)nb + 2) * 8);
     u64 active = 0;
     for (size_t i = 0; i < words; ++i) active += (u64)__builtin_popcount(bits[i]);
     for (u32 b = 0; b < nb; ++b) active += dw[b] != 0;
@@ -1961,7 +1976,8 @@ static int build_schedule(ksp_engine* e) {
     if (const char* sf = std::getenv("KSP_DEBUG_SHARES")) quarter_shares = std::max(1, std::atoi(sf));
     const u64 target = std::max<u64>(4 * total / ((u64)e->slots * quarter_shares * std::max<u32>(1, e->nparts)) + 1, 100000);
     // pass 2: shares
-    std::vector<u32> wg;
+    std::vector<u32>& wg = e->wg_host;
+    wg.clear();
     wg.reserve(A + (size_t)e->slots * 4);
     e->act_rec.resize(4 * (A + 1));
     u32 nsplit = 0;
@@ -1980,8 +1996,8 @@ static int build_schedule(ksp_engine* e) {
     r[0] = 0; r[1] = 0; r[2] = (u32)wg.size(); r[3] = nsplit;
     if ((rc = e->d_act.ensure(e->act_rec.size() * 4))) return rc;
     if ((rc = e->d_wg.ensure(std::max<size_t>(1, wg.size()) * 4))) return rc;
-    KSP_HIP(hipMemcpy(e->d_act.p, e->act_rec.data(), e->act_rec.size() * 4, hipMemcpyHostToDevice));
-    if (!wg.empty()) KSP_HIP(hipMemcpy(e->d_wg.p, wg.data(), wg.size() * 4, hipMemcpyHostToDevice));
+    KSP_HIP(hipMemcpyAsync(e->d_act.p, e->act_rec.data(), e->act_rec.size() * 4, hipMemcpyHostToDevice, e->sched_stream));
+    if (!wg.empty()) KSP_HIP(hipMemcpyAsync(e->d_wg.p, wg.data(), wg.size() * 4, hipMemcpyHostToDevice, e->sched_stream));
     e->sched_on = true;
     e->st.n_active_tiles = A;
     return KSP_OK;
@@ -2379,6 +2395,7 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     // silently runs only part of its blocks — seen with 30.5 M tiles on MI355X / ROCm 7.2)
     const u64 kMaxTilesPerLaunch = 4ull << 20;
     size_t act0 = 0, act1 = 0;
+    if (e->sched_on && st != e->sched_stream) KSP_HIP(hipStreamSynchronize(e->sched_stream));   // (work list uploaded on the build's stream)
     if (e->sched_on) {
         // work-list mode: the active tiles of [tile_begin, tile_end), each in its shares
         act0 = std::lower_bound(e->act_tid.begin(), e->act_tid.end(), tile_begin) - e->act_tid.begin();
