@@ -144,9 +144,14 @@ def main():
     cuts = eng.balanced_cuts(world)
     t0, t1 = cuts[rank], cuts[rank + 1]
     cap = int(min(eng.edge_bound(t0, t1), 1 << 27)) + 1
-    edges_d = torch.empty((cap, 16), dtype=torch.uint8, device=dev)
+    # double-buffered results: the D2H copy of step k runs on its own stream under stage 1 of step k + 1
+    edges_dd = [torch.empty((cap, 16), dtype=torch.uint8, device=dev) for _ in range(2)]
     host_cap = int(min(eng.edge_bound(0, eng.num_tiles), total_pairs, 1 << 27)) + 1
-    edges_h = torch.empty((host_cap, 16), dtype=torch.uint8).pin_memory() if rank == 0 else None
+    edges_hh = [torch.empty((host_cap, 16), dtype=torch.uint8).pin_memory() for _ in range(2)] if rank == 0 else None
+    copy_stream = torch.cuda.Stream(device=dev)
+    copied = [None, None]     # event: the D2H copy out of buffer i has finished
+    in_flight = [None, None]  # keeps the gathered device tensor alive until its copy is done
+    step_no = [0]
 
     stats = {"ms_join": 0.0, "ms_build": 0.0, "edges": 0, "stream_bytes": 0, "xchg_bytes": 0}
 
@@ -156,13 +161,25 @@ def main():
                                                              stream=stream.cuda_stream)
         else:
             eng.build_blocks(keys_d.data_ptr(), sk.offsets, stream=stream.cuda_stream)
+        buf = step_no[0] & 1
+        step_no[0] += 1
+        if copied[buf] is not None:
+            copied[buf].synchronize()       # the copy that last read this buffer pair (two steps ago)
+        edges_d, edges_h = edges_dd[buf], (edges_hh[buf] if rank == 0 else None)
         cnt = eng.join(t0, t1, edges_d.data_ptr(), cap, stream=stream.cuda_stream)
         local = edges_d[:cnt]
         if world > 1 and backend != "nccl":
             local = local.cpu()     # gloo exchanges host tensors (test hook only)
         allv = kdist.gather_edges(local, dst=0) if world > 1 else local
         if rank == 0:
-            edges_h[: allv.shape[0]].copy_(allv, non_blocking=False)
+            ready = torch.cuda.Event()
+            ready.record(stream)            # (the gather's kernels run on the compute stream)
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                edges_h[: allv.shape[0]].copy_(allv, non_blocking=True)
+                copied[buf] = torch.cuda.Event()
+                copied[buf].record(copy_stream)
+            in_flight[buf] = allv
         if record:
             st = eng.stats()
             stats["ms_join"] += st["ms_join"]
@@ -172,6 +189,7 @@ def main():
             stats["stream_bytes"] = st["last_stream_bytes"]
             stats["edges"] = int(allv.shape[0]) if rank == 0 else cnt
             if rank == 0 and os.environ.get("KSP_BENCH_CHECKSUM") == "1":
+                copy_stream.synchronize()
                 ev = edges_h[: allv.shape[0]].numpy().view(engine.EDGE_DTYPE).reshape(-1)
                 stats["checksum"] = int(ev["shared"].sum()) ^ (int(ev["source_1"].astype(np.int64).sum()) << 20) ^ int(
                     ev["source_2"].astype(np.int64).sum())
