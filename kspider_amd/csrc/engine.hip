@@ -289,23 +289,49 @@ struct PruneFn {
         return (single ? 0ull : 1ull) | ((u64)(head && !single) << 32);
     }
 };
+// Output "iterator" of the prune scan: instead of storing the packed prefix sums (and reading them back
+// in a second pass), the scan's store of element e moves entry e to its place among the kept entries.
 template <class V>
-__global__ void k_prune_scatter(const V* __restrict__ vals, const u64* __restrict__ ps, V* __restrict__ vals2,
-                                u32* __restrict__ rank2, u32* __restrict__ first, u64* __restrict__ scal, u64 n) {
-    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const u64 cur = ps[e], before = e ? ps[e - 1] : 0ull;
-    const u32 lo = (u32)cur, prev = (u32)before;
-    if (lo != prev) {   // kept entry
-        vals2[lo - 1] = vals[e];
-        rank2[lo - 1] = (u32)(cur >> 32) - 1u;
-        if ((cur >> 32) != (before >> 32)) first[(u32)(cur >> 32) - 1u] = lo - 1;   // first kept entry of its key
-    }
-    if (e == n - 1) {
-        scal[6] = lo;                 // kept entries
-        scal[2] = (u32)(cur >> 32);   // kept distinct keys (U)
-    }
-}
+struct PruneScatterIt {
+    using iterator_category = std::random_access_iterator_tag;
+    using value_type = u64;
+    using difference_type = std::ptrdiff_t;
+    using pointer = void;
+    struct Ctx {
+        const u64* keys;
+        const V* vals;
+        V* vals2;
+        u32* rank2;
+        u32* first;
+        u64* scal;
+        u64 n;
+    };
+    struct Ref {
+        Ctx c;
+        u64 e;
+        __device__ const Ref& operator=(const u64 cur) const {
+            const u64 f = PruneFn{c.keys, c.n}(e);
+            const u32 lo = (u32)cur, hi = (u32)(cur >> 32);
+            if (f & 1ull) {   // kept entry
+                c.vals2[lo - 1] = c.vals[e];
+                c.rank2[lo - 1] = hi - 1u;
+                if (f >> 32) c.first[hi - 1u] = lo - 1;   // first kept entry of its key
+            }
+            if (e == c.n - 1) {
+                c.scal[6] = lo;   // kept entries
+                c.scal[2] = hi;   // kept distinct keys (U)
+            }
+            return *this;
+        }
+    };
+    using reference = Ref;
+    Ctx c;
+    u64 base;
+    __host__ __device__ PruneScatterIt operator+(const std::ptrdiff_t d) const { return PruneScatterIt{c, base + (u64)d}; }
+    __host__ __device__ PruneScatterIt& operator+=(const std::ptrdiff_t d) { base += (u64)d; return *this; }
+    __device__ Ref operator[](const std::ptrdiff_t i) const { return Ref{c, base + (u64)i}; }
+    __device__ Ref operator*() const { return Ref{c, base}; }
+};
 
 // flag[e] = 1 when entry e opens a new (block, rank) group.
 template <class V>
@@ -1736,16 +1762,17 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                            d_ovf);
     }
     // singleton pruning + dense ranks of the kept keys (packed counters, one scan):  KA,VB -> R1 (ranks), VA (tags)
-    u64* ps = (u64*)e->KB.p;               // n packed prefix sums
+    // (the scan's output iterator scatters entry e as soon as its prefix sums are known: no second pass)
+    if ((rc = e->FK.ensure((nw / 2 + 8) * 4))) return rc;
+    u32* first = (u32*)e->FK.p;            // first kept entry of every rank (FK: the slice's input keys are dead after sort 1)
     {
         auto pf = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u64>(0), PruneFn{KA, nw});
+        PruneScatterIt<V> out{{KA, VB, VA, rank1, first, scal, nw}, 0};
         tb = 0;
-        KSP_HIP(rocprim::inclusive_scan(nullptr, tb, pf, ps, nw, rocprim::plus<u64>(), st));
+        KSP_HIP(rocprim::inclusive_scan(nullptr, tb, pf, out, nw, rocprim::plus<u64>(), st));
         if ((rc = e->tmp.ensure(tb))) return rc;
-        KSP_HIP(rocprim::inclusive_scan(e->tmp.p, tb, pf, ps, nw, rocprim::plus<u64>(), st));
+        KSP_HIP(rocprim::inclusive_scan(e->tmp.p, tb, pf, out, nw, rocprim::plus<u64>(), st));
     }
-    u32* first = (u32*)KA;                 // first kept entry of every rank (KA: the sorted keys are dead once the scan has run)
-    hipLaunchKernelGGL((k_prune_scatter<V>), dim3(grid_for(nw, bs)), dim3(bs), 0, st, VB, ps, VA, rank1, first, scal, nw);
     KSP_HIP(hipMemcpyAsync(e->h_scal + 6, scal + 6, 8, hipMemcpyDeviceToHost, st));
     KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
     m = e->h_scal[6];
