@@ -483,7 +483,7 @@ __global__ void k_list_pairs(const u32* __restrict__ brk, const u32* __restrict_
     const u32 b = blockIdx.x;
     const u32 cnt = blk_raw[b + 1] - blk_raw[b], src = blk_pos[b], dst = blk_raw[b];
     const u32 i0 = (u32)(((u64)cnt * blockIdx.y) / gridDim.y), i1 = (u32)(((u64)cnt * (blockIdx.y + 1)) / gridDim.y);
-    unsigned long long acc = 0;
+    unsigned long long acc = 0, holders = 0;
     for (u32 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         pr[dst + i] = brk[src + i];
         pb[dst + i] = b;
@@ -492,9 +492,13 @@ __global__ void k_list_pairs(const u32* __restrict__ brk, const u32* __restrict_
         if (inf >= BIG) { const uint4 m = bigmask[inf & ~BIG]; c = __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w); }
         else c = (inf >> 29) + 1;
         acc += (unsigned long long)c * (c - 1) / 2;
+        holders += c;
     }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&work[b], acc);
+    for (int o = 32; o > 0; o >>= 1) { acc += __shfl_down(acc, o); holders += __shfl_down(holders, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (acc) atomicAdd(&work[b], acc);
+        if (holders) atomicAdd(&work[gridDim.x], holders);   // slot nb: holders summed over all list words
+    }
 }
 // one byte per tile: plain idempotent stores (a few hundred active tiles take millions of hits —
 // atomics on the same words would serialise in L2)
@@ -616,6 +620,7 @@ struct JoinArgs {
     u32 ncell;          // fine cells per block (power of two, >= NP)
     const u32* blk_max; // nb: largest per-source k-mer count (weight sum) in the block
     const u32* inv;     // engine source index -> caller's source id
+    u32 collect;        // unweighted off-diagonal tiles: 1 = collect + bit-sliced accumulation, 0 = LDS counters
     // work-list mode (sched != NULL): only the block pairs that share a key are visited, and a
     // tile is cut into as many shares (rank ranges / key ranges) as its estimated work asks for
     const u32* sched;   // per workgroup of the whole work list: index of its active tile
@@ -1471,7 +1476,7 @@ __global__ __launch_bounds__(JW * 64, 6) void k_join(JoinArgs a) {   // (6 waves
     // 16-bit counters are exact iff one of the two blocks has no source with >= 2^16 k-mers
     if ((min(a.blk_max[I], a.blk_max[J]) < 65536u) != C16) return;
 
-    const bool popc = !W && (I == J || CELLS);
+    const bool popc = !W && a.collect && (I == J || CELLS);
     if (popc) {
         // unweighted tiles: bit-sliced accumulation in registers (no counter tile, no LDS atomics)
         u32* dst = tail_id != 0xFFFFFFFFu ? a.tailbuf + (size_t)tail_id * (TB * TB) : nullptr;
@@ -1604,6 +1609,8 @@ struct ksp_engine {
     ksp::Buf d_off, KA, KB, VA, VB, R1, FK, FT, asm_small, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, blk_max, part, scalars, count, tailbuf, smap;
     u32 slots = 0;                // workgroups of k_join the chip holds at once (occupancy x CUs)
     // work list of the join (built by finish_build; empty -> dense mode: every tile is visited)
+    bool collect = false;         // unweighted off-diagonal tiles: collect matches + bit-sliced accumulation (multi-source
+                                  // postings dominate) instead of LDS counters (single-source postings dominate)
     bool sched_on = false;
     hipStream_t sched_stream = nullptr;   // stream of the build that produced the work list (its uploads are ordered on it)
     bool have_bits = false;       // tbits / dwork hold this build's tile bitmap and diagonal work
@@ -1958,6 +1965,7 @@ static int query_slots(ksp_engine* e) {
 // pair update of a diagonal tile, ~2000 per workgroup (zeroing and flushing the counter tile).
 static int build_schedule(ksp_engine* e) {
     e->sched_on = false;
+    e->collect = false;
     e->act_tid.clear(); e->act_rec.clear();
     e->st.n_active_tiles = e->st.n_tiles;
     if (!e->have_bits) return KSP_OK;
@@ -1967,6 +1975,11 @@ static int build_schedule(ksp_engine* e) {
     // (copied to pinned memory by launch_sched_kernels; the build has been synchronised since)
     const unsigned long long* dw = reinterpret_cast<const unsigned long long*>(e->h_stage);
     const u32* bits = reinterpret_cast<const u32*>(e->h_stage + ((size_t)nb + 2) * 8);
+    // average holders per list word: expanding a match of two k-holder postings costs k^2 counter updates,
+    // collecting it costs the same whatever k is — worth it from about two holders per word (measured on
+    // C2: 13 holders/word after the source reordering -> 0.46 vs 1.1 ms; 1.2 in the caller's order -> 20 vs 5 ms)
+    e->collect = !e->weighted && e->h_scal_words && dw[nb] >= 2 * e->h_scal_words;
+    if (const char* cm = std::getenv("KSP_COLLECT")) e->collect = !e->weighted && std::atoi(cm) != 0;   // diagnostic / tests
     u64 active = 0;
     for (size_t i = 0; i < words; ++i) active += (u64)__builtin_popcount(bits[i]);
     for (u32 b = 0; b < nb; ++b) active += dw[b] != 0;
@@ -2409,6 +2422,7 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     a.blk_max = e->blk_max.as<u32>();
     a.inv = e->smap.as<u32>() + 3 * (((size_t)e->n_sources + 64) & ~(size_t)63);
     a.sched = nullptr; a.act = nullptr; a.wg0 = 0; a.split0 = 0; a.tail_done = nullptr;
+    a.collect = e->collect ? 1u : 0u;
     auto launch = [&](bool c16, dim3 grid, const JoinArgs& args) {
         if (e->use_cells) {
             if (e->weighted) { if (c16) hipLaunchKernelGGL((k_join<true, true, true>), grid, block, 0, st, args); else hipLaunchKernelGGL((k_join<true, false, true>), grid, block, 0, st, args); }

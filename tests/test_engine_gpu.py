@@ -10,17 +10,22 @@ from kspider_amd import engine, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default", "no_reorder", "dense_walk"])
+@pytest.fixture(autouse=True, params=["default", "no_reorder", "dense_walk", "collect", "lds_counters"])
 def mode(request, monkeypatch):
-    """Every case runs three ways: as shipped (sources reordered by shared-key label, join over the
-    work list of active tiles), with the caller's source order (KSP_REORDER=0), and with the
-    reordering but a plain walk over all tiles (KSP_NO_SCHED=1)."""
-    monkeypatch.delenv("KSP_REORDER", raising=False)
-    monkeypatch.delenv("KSP_NO_SCHED", raising=False)
+    """Every case runs five ways: as shipped (sources reordered by shared-key label, join over the
+    work list of active tiles, accumulation chosen by the postings' sizes), with the caller's source
+    order (KSP_REORDER=0), with the reordering but a plain walk over all tiles (KSP_NO_SCHED=1), and with
+    the off-diagonal accumulation forced to the bit-sliced collect path / to the LDS counters."""
+    for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT"):
+        monkeypatch.delenv(k, raising=False)
     if request.param == "no_reorder":
         monkeypatch.setenv("KSP_REORDER", "0")
     elif request.param == "dense_walk":
         monkeypatch.setenv("KSP_NO_SCHED", "1")
+    elif request.param == "collect":
+        monkeypatch.setenv("KSP_COLLECT", "1")
+    elif request.param == "lds_counters":
+        monkeypatch.setenv("KSP_COLLECT", "0")
     return request.param
 
 
