@@ -98,6 +98,15 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
 
 int ksp_engine_get_stats(const ksp_engine* e, ksp_stats* out);
 
+/* Stage 1 from an inverted index instead of sketches: key k is held by the sources
+ * d_sources[h_key_off[k] .. h_key_off[k+1]) (dense source indices, distinct inside a key, at least two per
+ * key; keys in any order) and weighs d_key_weights[k] (NULL: 1).  This is exactly the reference's input —
+ * `_color_to_sources.bin` + `_color_count.bin`, src/pairwise.cpp:128-170 — so the drop-in path hands its
+ * colours over without transposing them into per-source runs and skips the engine's sort and prune.
+ * The caller guarantees that every source's weights sum to less than 2^32.  Then ksp_engine_join as usual. */
+int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const uint32_t* d_sources,
+                              const uint32_t* d_key_weights, uint32_t n_keys, uint32_t n_sources, void* stream);
+
 /* ---- stage 1 sharded over GPUs (one process per GPU) ---------------------------------------
  * Every rank holds the full sketch set; rank `part` of `nparts` sorts and prunes the keys of its
  * 1/nparts share of the hash range only (ksp_engine_build_slice).  The engine orders the sources by a
@@ -138,6 +147,10 @@ int ksp_memcpy_d2h(void* h_dst, const void* d_src, uint64_t bytes);
 /* ---- host-buffer convenience (H2D + both stages + D2H), edges sorted by (s1, s2) ---- */
 int ksp_pairwise_host(const uint64_t* keys, const uint32_t* weights, const uint64_t* offsets, uint32_t n_sources,
                       int device, ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats);
+/* Same for an inverted index in host memory (see ksp_engine_build_postings). */
+int ksp_pairwise_postings_host(const uint64_t* key_off, const uint32_t* sources, const uint32_t* key_weights,
+                               uint32_t n_keys, uint32_t n_sources, int device, ksp_edge** out_edges,
+                               uint64_t* n_edges, ksp_stats* stats);
 void ksp_free(void* p);
 
 /* ---- the reference entry point ------------------------------------------------------

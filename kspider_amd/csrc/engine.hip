@@ -121,6 +121,23 @@ __global__ void k_label(const u32* __restrict__ rk, const V* __restrict__ vals, 
     const u32 f = src_of_tag((u32)vals[first[rk[e]]]);   // entries of a key are in ascending source order
     if (f < label[s]) atomicMin(&label[s], f);
 }
+// Postings input (an inverted index: per key its holders, e.g. the reference's colour -> sources map):
+// the state stage 1 reaches after sorting and pruning, written directly — entry tags, the key index as
+// rank, and per source the bound of its pair counters (k-mer count / weight sum).
+template <class V, bool W>
+__global__ void k_post_expand(const u32* __restrict__ koff, const u32* __restrict__ src, const u32* __restrict__ kw,
+                              V* __restrict__ vals, u32* __restrict__ rk, u32* __restrict__ src_bound, u32 n_keys) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_keys) return;
+    const u32 w = W ? kw[r] : 1u;
+    for (u32 e = koff[r]; e < koff[r + 1]; ++e) {
+        const u32 s = src[e];
+        const u32 tag = ((s / TB) << 8) | (s % TB);
+        vals[e] = W ? (V)(((u64)w << 32) | tag) : (V)tag;
+        rk[e] = r;
+        if (w) atomicAdd(&src_bound[s], w);   // (the caller guarantees sums below 2^32)
+    }
+}
 // order[i] = i-th source in (label, id) order  ->  newidx[order[i]] = i; order itself is the inverse map
 __global__ void k_perm(const u32* __restrict__ order, u32* __restrict__ newidx, u32 n) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1594,6 +1611,8 @@ struct ksp_engine {
     u64 max_key = 0;
     bool have_max_key = false;
     bool slice_ready = false;
+    const u32 *post_off = nullptr, *post_src = nullptr, *post_w = nullptr;   // postings input of the build in progress (device)
+    u32 post_nkeys = 0;
     int slice_phase = 0;          // 1: build_slice done, waiting for ksp_engine_slice_finish
     u64 slice_hdr[4] = {0, 0, 0, 0};   // padded length, distinct keys (U), big postings, block keys
     u32 ncell = ksp::NP;          // fine rank cells per block (power of two)
@@ -1636,7 +1655,8 @@ static inline unsigned grid_for(u64 n, unsigned bs) { return (unsigned)((n + bs 
 template <bool W>
 static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStream_t st, const int phase) {
     // phase 0: the whole of stage 1;  1: up to the source labels (key-range slice, before the labels of all
-    // slices are combined);  2: the rest (source order from the final labels, block lists)
+    // slices are combined);  2: the rest (source order from the final labels, block lists);  3: postings
+    // input (ksp_engine_build_postings: sorting and pruning are already done by the caller's inverted index)
     typedef typename std::conditional<W, u64, u32>::type V;
     const u64 n = e->n_entries;
     const u32 N = e->n_sources, nb = e->nb;
@@ -1678,7 +1698,29 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     while ((1u << bbits) < nb) ++bbits;
     size_t tb = 0;
     u64 m = e->n_kept;   // (phase 2: set by phase 1)
-    if (phase != 2) {
+    if (phase == 3) {
+        m = n;
+        e->n_kept = m;
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, iota, N);
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, N);
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, newidx, N);
+        hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, label, N);
+        KSP_HIP(hipMemsetAsync(e->blk_max.p, 0, ((size_t)nb + 1) * 4, st));
+        KSP_HIP(hipMemsetAsync(sbound, 0, (size_t)N * 4, st));
+        const u32 nk = e->post_nkeys;
+        hipLaunchKernelGGL((k_post_expand<V, W>), dim3(grid_for(nk, bs)), dim3(bs), 0, st, e->post_off, e->post_src,
+                           e->post_w, VA, rank1, sbound, nk);
+        {   // U = number of keys (what the prune scan reports on the sketch path)
+            e->h_scal[2] = nk;
+            KSP_HIP(hipMemcpyAsync(scal + 2, e->h_scal + 2, 8, hipMemcpyHostToDevice, st));
+        }
+        if (reorder) {
+            const u32 skip = m / std::max<u32>(1, N) >= 512 ? 7u : 0u;
+            hipLaunchKernelGGL((k_label<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, VA, e->post_off, label, skip, m);
+        } else {
+            hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
+        }
+    } else if (phase != 2) {
 
     // key range (one 8-byte D2H, unless the caller passed key_bits)
     if (e->key_bits <= 0) {
@@ -2144,6 +2186,86 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     return KSP_OK;
 }
 
+int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const uint32_t* d_sources,
+                              const uint32_t* d_key_weights, uint32_t n_keys, uint32_t n_sources, void* stream) {
+    if (!e || (n_keys && (!h_key_off || !d_sources))) { set_error("build_postings: NULL argument"); return KSP_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    KSP_HIP(hipSetDevice(e->device));
+    e->built = false;
+    e->slice_ready = false;
+    e->slice_phase = 0;
+    const u64 n = n_keys ? h_key_off[n_keys] : 0;
+    if (n_keys && h_key_off[0] != 0) { set_error("build_postings: key_off[0] must be 0"); return KSP_E_ARG; }
+    for (u32 k = 0; k < n_keys; ++k)
+        if (h_key_off[k + 1] < h_key_off[k] + 2) { set_error("build_postings: every key needs at least two holders"); return KSP_E_ARG; }
+    if (n >= (1ull << 30)) { set_error("build_postings: more than 2^30 entries per call"); return KSP_E_LIMIT; }
+    e->n_sources = n_sources;
+    e->n_entries = n;
+    e->nb = (n_sources + TB - 1) / TB;
+    e->weighted = d_key_weights != nullptr;
+    e->key_bits = 0;
+    e->have_max_key = false;
+    e->nparts = 1;
+    e->part_id = 0;
+    e->h_off.clear();
+    e->st = ksp_stats{};
+    e->st.n_sources = n_sources;
+    e->st.n_entries = n;
+    e->sort_entries = 0;
+    e->st.n_blocks = e->nb;
+    e->st.n_tiles = (u64)e->nb * (e->nb + 1) / 2;
+    e->st.weighted = e->weighted;
+    e->n_kept = 0;
+    e->h_blk_off.assign((size_t)e->nb + 1, 0);
+    e->h_blk_max.assign((size_t)e->nb + 1, 0);
+    e->have_bits = false;
+    if (n == 0 || e->nb == 0) {   // nothing can intersect
+        e->st.n_block_keys = 0;
+        e->need32 = false;
+        e->built = true;
+        return KSP_OK;
+    }
+    int rc;
+    KSP_HIP(hipEventRecord(e->ev[0], st));
+    {   // fine cells as in build_common, from the mean block size (the holders are not grouped by source here)
+        const u64 dmax = 2 * (n / e->nb + 1);
+        u32 nc = NP;
+        while ((u64)nc * 32 < dmax && nc < (1u << 17)) nc <<= 1;
+        while (nc > NP && (u64)nc * e->nb > (1ull << 28)) nc >>= 1;
+        e->ncell = nc;
+        const char* jm = std::getenv("KSP_JOIN");
+        e->use_cells = !(jm && std::string(jm) == "window");
+    }
+    if ((rc = e->blk_max.ensure(((size_t)e->nb + 2) * 4))) return rc;
+    if (const char* ro = std::getenv("KSP_REORDER")) e->reorder = std::atoi(ro) != 0;
+    // key offsets as 32-bit device array (= first entry of every rank)
+    if ((rc = e->d_off.ensure(((size_t)n_keys + 2) * 4))) return rc;
+    {
+        std::vector<u32> off32((size_t)n_keys + 1);
+        for (u32 k = 0; k <= n_keys; ++k) off32[k] = (u32)h_key_off[k];
+        KSP_HIP(hipMemcpyAsync(e->d_off.p, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, st));
+        KSP_HIP(hipStreamSynchronize(st));   // (off32 is a local)
+    }
+    e->post_off = e->d_off.as<u32>();
+    e->post_src = d_sources;
+    e->post_w = d_key_weights;
+    e->post_nkeys = n_keys;
+    rc = e->weighted ? build_impl<true>(e, nullptr, nullptr, st, 3) : build_impl<false>(e, nullptr, nullptr, st, 3);
+    e->post_off = e->post_src = e->post_w = nullptr;
+    if (rc) return rc;
+    KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 64, hipMemcpyDeviceToHost, st));
+    KSP_HIP(hipStreamSynchronize(st));
+    if (e->n_kept) {
+        e->h_scal_words = e->h_scal[1];
+        e->h_scal_keys = e->h_scal[2];
+        if ((rc = launch_sched_kernels(e, st))) return rc;
+    }
+    KSP_HIP(hipEventRecord(e->ev[1], st));
+    KSP_HIP(hipStreamSynchronize(st));
+    KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
+    return finish_build(e);
+}
+
 int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights,
                             const uint64_t* h_offsets, uint32_t n_sources, int key_bits, void* stream) {
     int rc = build_common(e, d_keys, d_weights, h_offsets, n_sources, key_bits, 0, 1, (hipStream_t)stream);
@@ -2572,38 +2694,17 @@ int ksp_memcpy_d2h(void* h, const void* d, uint64_t bytes) {
 
 void ksp_free(void* p) { std::free(p); }
 
-int ksp_pairwise_host(const uint64_t* keys, const uint32_t* weights, const uint64_t* offsets, uint32_t n_sources,
-                      int device, ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats) {
-    if (!offsets || !out_edges || !n_edges) { set_error("pairwise_host: NULL argument"); return KSP_E_ARG; }
-    *out_edges = nullptr;
-    *n_edges = 0;
-    ksp_engine* e = nullptr;
-    int rc = ksp_engine_create(device, &e);
-    if (rc) return rc;
-    const u64 n = n_sources ? offsets[n_sources] : 0;
-    void *d_keys = nullptr, *d_w = nullptr, *d_edges = nullptr;
+// join every tile of a built engine and bring the edges to the host, sorted by (source_1, source_2)
+static int collect_all_edges(ksp_engine* e, int device, ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats) {
+    void* d_edges = nullptr;
     std::vector<ksp_edge> all;
-    auto cleanup = [&]() {
-        if (d_keys) (void)hipFree(d_keys);
-        if (d_w) (void)hipFree(d_w);
-        if (d_edges) (void)hipFree(d_edges);
-        ksp_engine_destroy(e);
-    };
+    int rc = KSP_OK;
     do {
-        if (n) {
-            if ((rc = ksp_device_malloc(device, n * 8, &d_keys))) break;
-            if ((rc = ksp_memcpy_h2d(d_keys, keys, n * 8))) break;
-            if (weights) {
-                if ((rc = ksp_device_malloc(device, n * 4, &d_w))) break;
-                if ((rc = ksp_memcpy_h2d(d_w, weights, n * 4))) break;
-            }
-        }
-        if ((rc = ksp_engine_build_blocks(e, (const u64*)d_keys, (const u32*)d_w, offsets, n_sources, 0, nullptr))) break;
         // Tile ranges as large as possible: start with everything; when the edge buffer overflows, grow it
         // to the reported count if memory allows, otherwise halve the range (sparse inputs need one launch,
         // dense ones are cut into ranges whose non-zero pairs fit).
         const u64 T = ksp_engine_num_tiles(e);
-        u64 cap = 1ull << 24;   // 16 Mi edges = 256 MiB to begin with
+        u64 cap = std::min<u64>(1ull << 24, ksp_engine_edge_bound(e, 0, T) + 1);   // at most 256 MiB to begin with
         if ((rc = ksp_device_malloc(device, cap * sizeof(ksp_edge), &d_edges))) break;
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
@@ -2657,7 +2758,66 @@ int ksp_pairwise_host(const uint64_t* keys, const uint32_t* weights, const uint6
         *out_edges = out;
         *n_edges = all.size();
     } while (0);
-    cleanup();
+    if (d_edges) (void)hipFree(d_edges);
+    return rc;
+}
+
+int ksp_pairwise_host(const uint64_t* keys, const uint32_t* weights, const uint64_t* offsets, uint32_t n_sources,
+                      int device, ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats) {
+    if (!offsets || !out_edges || !n_edges) { set_error("pairwise_host: NULL argument"); return KSP_E_ARG; }
+    *out_edges = nullptr;
+    *n_edges = 0;
+    ksp_engine* e = nullptr;
+    int rc = ksp_engine_create(device, &e);
+    if (rc) return rc;
+    const u64 n = n_sources ? offsets[n_sources] : 0;
+    void *d_keys = nullptr, *d_w = nullptr;
+    do {
+        if (n) {
+            if ((rc = ksp_device_malloc(device, n * 8, &d_keys))) break;
+            if ((rc = ksp_memcpy_h2d(d_keys, keys, n * 8))) break;
+            if (weights) {
+                if ((rc = ksp_device_malloc(device, n * 4, &d_w))) break;
+                if ((rc = ksp_memcpy_h2d(d_w, weights, n * 4))) break;
+            }
+        }
+        if ((rc = ksp_engine_build_blocks(e, (const u64*)d_keys, (const u32*)d_w, offsets, n_sources, 0, nullptr))) break;
+        rc = collect_all_edges(e, device, out_edges, n_edges, stats);
+    } while (0);
+    if (d_keys) (void)hipFree(d_keys);
+    if (d_w) (void)hipFree(d_w);
+    ksp_engine_destroy(e);
+    return rc;
+}
+
+int ksp_pairwise_postings_host(const uint64_t* key_off, const uint32_t* sources, const uint32_t* key_weights,
+                               uint32_t n_keys, uint32_t n_sources, int device, ksp_edge** out_edges,
+                               uint64_t* n_edges, ksp_stats* stats) {
+    if (!out_edges || !n_edges || (n_keys && (!key_off || !sources))) { set_error("pairwise_postings_host: NULL argument"); return KSP_E_ARG; }
+    *out_edges = nullptr;
+    *n_edges = 0;
+    ksp_engine* e = nullptr;
+    int rc = ksp_engine_create(device, &e);
+    if (rc) return rc;
+    const u64 n = n_keys ? key_off[n_keys] : 0;
+    for (u64 i = 0; i < n; ++i)
+        if (sources[i] >= n_sources) { set_error("pairwise_postings_host: source index out of range"); ksp_engine_destroy(e); return KSP_E_ARG; }
+    void *d_src = nullptr, *d_w = nullptr;
+    do {
+        if (n) {
+            if ((rc = ksp_device_malloc(device, n * 4, &d_src))) break;
+            if ((rc = ksp_memcpy_h2d(d_src, sources, n * 4))) break;
+            if (key_weights) {
+                if ((rc = ksp_device_malloc(device, (u64)n_keys * 4, &d_w))) break;
+                if ((rc = ksp_memcpy_h2d(d_w, key_weights, (u64)n_keys * 4))) break;
+            }
+        }
+        if ((rc = ksp_engine_build_postings(e, key_off, (const u32*)d_src, (const u32*)d_w, n_keys, n_sources, nullptr))) break;
+        rc = collect_all_edges(e, device, out_edges, n_edges, stats);
+    } while (0);
+    if (d_src) (void)hipFree(d_src);
+    if (d_w) (void)hipFree(d_w);
+    ksp_engine_destroy(e);
     return rc;
 }
 

@@ -67,20 +67,24 @@ int run_pairwise(const std::string& prefix, int user_threads) {
         return dense_of.empty() ? (uint32_t)(std::lower_bound(ids.begin(), ids.end(), g) - ids.begin()) : dense_of[g];
     };
 
-    // colours in ascending id order -> every source's run of colour ids is sorted
-    std::vector<uint32_t> order(ix.colors.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
-    std::sort(order.begin(), order.end(),
-              [&](uint32_t a, uint32_t b) { return ix.colors[a].first < ix.colors[b].first; });
-    std::vector<uint64_t> offsets((size_t)N + 1, 0);
+    // The colour index IS an inverted index (colour -> sources, src/pairwise.cpp:128-170): hand it to the
+    // engine as postings — no transposition into per-source runs, no sort and prune on the device.
     std::vector<std::pair<uint32_t, uint32_t>> zero_pairs;   // pairs touched only through weight-0 colours
     std::vector<uint64_t> wsum((size_t)N, 0);
-    std::vector<uint32_t> weight_of(ix.colors.size(), 0);
+    std::vector<uint64_t> key_off;
+    std::vector<uint32_t> post_src, key_w;
+    key_off.push_back(0);
+    {
+        size_t total = 0;
+        for (auto& c : ix.colors) total += c.second.size() >= 2 ? c.second.size() : 0;
+        post_src.reserve(total);
+        key_off.reserve(ix.colors.size() + 1);
+        key_w.reserve(ix.colors.size());
+    }
     for (size_t ci = 0; ci < ix.colors.size(); ++ci) {
         auto& c = ix.colors[ci];
         auto it = ix.colors_count.find(c.first);   // colorsCount[item.first] (:221): 0 when absent
         const uint32_t w = it == ix.colors_count.end() ? 0 : it->second;
-        weight_of[ci] = w;
         if (c.second.size() < 2) continue;          // a colour with one source produces no pair
         if (w == 0) {
             // the reference still creates the pair entries (with += 0): remember them
@@ -94,33 +98,19 @@ int run_pairwise(const std::string& prefix, int user_threads) {
         }
         for (uint32_t g : c.second) {
             const uint32_t di = dense(g);
-            offsets[di + 1]++;
+            post_src.push_back(di);
             wsum[di] += w;
         }
+        key_off.push_back(post_src.size());
+        key_w.push_back(w);
     }
-    for (uint32_t s = 0; s < N; ++s) {
+    for (uint32_t s = 0; s < N; ++s)
         if (wsum[s] >= (1ull << 32))
             throw std::runtime_error("kspider_amd: colour weights of group " + std::to_string(ids[s]) +
                                      " sum to >= 2^32 (32-bit pair counters would overflow)");
-        offsets[s + 1] += offsets[s];
-    }
-    const uint64_t E = offsets[N];
-    std::vector<uint64_t> keys(E);
-    std::vector<uint32_t> wts(E);
-    {
-        std::vector<uint64_t> cur(offsets.begin(), offsets.end() - 1);
-        for (uint32_t ci : order) {
-            auto& c = ix.colors[ci];
-            if (c.second.size() < 2 || weight_of[ci] == 0) continue;
-            for (uint32_t g : c.second) {
-                uint64_t at = cur[dense(g)]++;
-                keys[at] = c.first;
-                wts[at] = weight_of[ci];
-            }
-        }
-    }
-    // duplicates of one source inside a colour cannot occur (flat_hash_set), but two colours
-    // may narrow to the same uint32 id only via insert_or_assign, which load_index resolved.
+    const uint64_t E = post_src.size();
+    // (a source cannot repeat inside a colour: flat_hash_set; two colours narrowing to the same uint32 id
+    //  were resolved by load_index the way insert_or_assign does)
 
     const double t_transpose = since(t0);
     int device = 0;
@@ -129,7 +119,8 @@ int run_pairwise(const std::string& prefix, int user_threads) {
     uint64_t n_edges = 0;
     ksp_stats st;
     auto t1 = Clock::now();
-    int rc = ksp_pairwise_host(keys.data(), wts.data(), offsets.data(), N, device, &edges, &n_edges, &st);
+    int rc = ksp_pairwise_postings_host(key_off.data(), post_src.data(), key_w.data(), (uint32_t)key_w.size(), N, device,
+                                        &edges, &n_edges, &st);
     const double t_device = since(t1);
     if (rc != KSP_OK) return rc;
     std::vector<ksp::EdgeRow> rows;
@@ -155,7 +146,7 @@ int run_pairwise(const std::string& prefix, int user_threads) {
     }
     std::cout << "pairwise hashmap construction: " << since(t0) << " secs" << std::endl;
     if (std::getenv("KSPIDER_VERBOSE"))
-        std::cout << "kspider_amd: host transposition " << t_transpose << " s, device round trip " << t_device
+        std::cout << "kspider_amd: postings from the colour index " << t_transpose << " s, device round trip " << t_device
                   << " s (stage 1 " << st.ms_build << " ms, join " << st.ms_join << " ms)" << std::endl;
     std::cout << "writing pairwise matrix to " << prefix << "_kSpider_pairwise.tsv" << std::endl;
     ksp::write_pairwise_tsv(prefix, rows, kmer_count, user_threads);

@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "kspider_pairwise_sigs", "kspider_pairwise_bins",
     "ksp_engine_build_slice", "ksp_engine_slice_sizes", "ksp_engine_slice_export", "ksp_engine_assemble",
     "ksp_engine_edge_bound", "ksp_engine_slice_labels", "ksp_engine_slice_finish", "ksp_engine_balanced_cuts",
+    "ksp_engine_build_postings", "ksp_pairwise_postings_host",
 ]
 
 
@@ -95,6 +96,11 @@ def lib():
                                         ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(Stats)]
         L.ksp_free.argtypes = [ctypes.c_void_p]
+        L.ksp_engine_build_postings.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
+        L.ksp_pairwise_postings_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                                 ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                                 ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(Stats)]
         L.ksp_free.restype = None
         L.kspider_pairwise.argtypes = [ctypes.c_char_p, ctypes.c_int]
         L.ksp_index_info.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
@@ -150,6 +156,27 @@ def pairwise_bins(bins_dir: str, out_prefix: str | None = None, user_threads: in
     """phmap flat_hash_set<uint64> sketch dumps (*.bin) -> pairwise TSVs."""
     _check(lib().kspider_pairwise_bins(os.fsencode(bins_dir), os.fsencode(out_prefix) if out_prefix else None,
                                        int(user_threads)))
+
+
+def pairwise_postings_host(key_off: np.ndarray, sources: np.ndarray, key_weights: np.ndarray | None, n_sources: int,
+                           device: int = 0):
+    """Inverted index (key k held by sources[key_off[k]:key_off[k+1]], weight key_weights[k] or 1) ->
+    (edges sorted by (source_1, source_2), stats).  What the drop-in path feeds the engine."""
+    key_off = np.ascontiguousarray(key_off, dtype=np.uint64)
+    sources = np.ascontiguousarray(sources, dtype=np.uint32)
+    kw = None if key_weights is None else np.ascontiguousarray(key_weights, dtype=np.uint32)
+    out = ctypes.c_void_p()
+    n = ctypes.c_uint64(0)
+    st = Stats()
+    _check(lib().ksp_pairwise_postings_host(key_off.ctypes.data, sources.ctypes.data, kw.ctypes.data if kw is not None else None,
+                                            key_off.size - 1, n_sources, device, ctypes.byref(out), ctypes.byref(n),
+                                            ctypes.byref(st)))
+    try:
+        buf = (ctypes.c_char * (n.value * EDGE_DTYPE.itemsize)).from_address(out.value) if n.value else b""
+        edges = np.frombuffer(buf, dtype=EDGE_DTYPE).copy()
+    finally:
+        lib().ksp_free(out)
+    return edges, st.as_dict()
 
 
 def index_info(index_prefix: str) -> dict:

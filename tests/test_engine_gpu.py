@@ -162,3 +162,40 @@ def test_label_structures(oracle_lib):
         runs.append(sorted(set(own + chain + fam + hub)))
     runs += [[90_000_000 + i] for i in range(40)]                   # loners
     _check(synth.from_runs(runs), oracle_lib)
+
+
+def test_postings_input_equals_sketch_input(oracle_lib):
+    """The inverted-index entry (what the drop-in path feeds) against the sketch entry and the oracle:
+    unweighted and weighted, keys in scrambled order, holders of a key in scrambled order."""
+    sk = synth.generate("C2", n_sources=500, mean_size=400, cluster_cap=60, seed=909)
+    n = sk.n_sources
+    src = np.repeat(np.arange(n, dtype=np.uint32), np.diff(sk.offsets).astype(np.int64))
+    order = np.argsort(sk.keys, kind="stable")
+    k, s = sk.keys[order], src[order]
+    uniq, start, cnt = np.unique(k, return_index=True, return_counts=True)
+    rng = np.random.default_rng(3)
+    groups = [rng.permutation(s[a:a + c]) for a, c in zip(start, cnt) if c >= 2]
+    wts = rng.integers(0, 50, size=len(groups), dtype=np.uint32)           # some zero weights
+    perm = rng.permutation(len(groups))
+    groups = [groups[i] for i in perm]
+    wts = wts[perm]
+    key_off = np.zeros(len(groups) + 1, dtype=np.uint64)
+    key_off[1:] = np.cumsum([g.size for g in groups])
+    sources = np.concatenate(groups).astype(np.uint32)
+    edges, st = engine.pairwise_postings_host(key_off, sources, None, n)
+    ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
+    assert len(edges) == len(ref) and (edges == ref).all()
+    # weighted: sum of the weights of the shared keys
+    edges_w, st = engine.pairwise_postings_host(key_off, sources, wts, n)
+    want = {}
+    for g, w in zip(groups, wts):
+        gs = np.sort(g)
+        for x in range(gs.size):
+            for y in range(x + 1, gs.size):
+                want[(int(gs[x]), int(gs[y]))] = want.get((int(gs[x]), int(gs[y])), 0) + int(w)
+    want = {p: v for p, v in want.items() if v}
+    got = {(int(e["source_1"]), int(e["source_2"])): int(e["shared"]) for e in edges_w}
+    assert got == want
+    # no key at all
+    e0, _ = engine.pairwise_postings_host(np.zeros(1, dtype=np.uint64), np.zeros(0, dtype=np.uint32), None, n)
+    assert len(e0) == 0
