@@ -350,21 +350,24 @@ struct PruneScatterIt {
     __device__ Ref operator*() const { return Ref{c, base}; }
 };
 
-// flag[e] = 1 when entry e opens a new (block, rank) group.
+// 1 when entry e opens a new (block, rank) group; evaluated on the fly by the scan and the passes after it
+// (two neighbouring loads of two arrays) instead of being written out by a pass of its own
 template <class V>
-__global__ void k_heads(const u32* __restrict__ rk, const V* __restrict__ vals, u32* __restrict__ flag, u64 n) {
-    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    u32 f = 1;
-    if (e > 0) f = ((tag_of(vals[e]) >> 8) != (tag_of(vals[e - 1]) >> 8)) || (rk[e] != rk[e - 1]);
-    flag[e] = f;
-}
+struct HeadFn {
+    const u32* rk;
+    const V* vals;
+    __device__ u32 operator()(u64 e) const {
+        if (e == 0) return 1u;
+        return ((tag_of(vals[e]) >> 8) != (tag_of(vals[e - 1]) >> 8)) || (rk[e] != rk[e - 1]) ? 1u : 0u;
+    }
+};
 
 // scal[1] = Ktot (distinct (block, key) groups), estart[Ktot] = n.
-__global__ void k_ktot(const u32* __restrict__ flag, const u32* __restrict__ didx, u32* __restrict__ estart,
+template <class V>
+__global__ void k_ktot(const HeadFn<V> head, const u32* __restrict__ didx, u32* __restrict__ estart,
                        u64* __restrict__ scal, u64 n) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        u32 k = didx[n - 1] + flag[n - 1];
+        u32 k = didx[n - 1] + head(n - 1);
         estart[k] = (u32)n;
         scal[1] = k;
     }
@@ -416,12 +419,12 @@ __global__ void k_fill(u32* __restrict__ p, u32 v, u64 n) {
 
 // distinct ranks of every block (padded layout) + first entry of each group.
 template <class V>
-__global__ void k_emit_keys(const u32* __restrict__ rk, const V* __restrict__ vals, const u32* __restrict__ flag,
+__global__ void k_emit_keys(const u32* __restrict__ rk, const V* __restrict__ vals, const HeadFn<V> head,
                             const u32* __restrict__ didx, const u32* __restrict__ blk_raw,
                             const u32* __restrict__ blk_pos, u32* __restrict__ brk, u32* __restrict__ estart, u64 n) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    if (flag[e]) {
+    if (head(e)) {
         u32 d = didx[e], b = tag_of(vals[e]) >> 8;
         brk[blk_pos[b] + (d - blk_raw[b])] = rk[e];
         estart[d] = (u32)e;
@@ -1859,23 +1862,24 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     u32* flag = (u32*)VA;
     u32* didx = (u32*)e->KB.p;             // m
     u32* estart = (u32*)e->KB.p + (n + 2); // up to m+1
-    hipLaunchKernelGGL((k_heads<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rk2, T, flag, m);
+    const HeadFn<V> head{rk2, T};
+    auto hf = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u64>(0), head);
     tb = 0;
-    KSP_HIP(rocprim::exclusive_scan(nullptr, tb, flag, didx, (u32)0, m, rocprim::plus<u32>(), st));
+    KSP_HIP(rocprim::exclusive_scan(nullptr, tb, hf, didx, (u32)0, m, rocprim::plus<u32>(), st));
     if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, flag, didx, (u32)0, m, rocprim::plus<u32>(), st));
-    hipLaunchKernelGGL(k_ktot, dim3(1), dim3(64), 0, st, flag, didx, estart, scal, m);
+    KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, hf, didx, (u32)0, m, rocprim::plus<u32>(), st));
+    hipLaunchKernelGGL((k_ktot<V>), dim3(1), dim3(64), 0, st, head, didx, estart, scal, m);
     hipLaunchKernelGGL((k_blk_raw<V>), dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, T, didx, scal, blk_raw, nb, m);
     hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, blk_raw, blk_pos, scal, nb);
     hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
-    hipLaunchKernelGGL((k_emit_keys<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rk2, T, flag, didx, blk_raw,
+    hipLaunchKernelGGL((k_emit_keys<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rk2, T, head, didx, blk_raw,
                        blk_pos, e->bkeys.as<u32>(), estart, m);
     // the number of distinct (block, key) groups sizes the posting passes (after the source reordering it is
     // an order of magnitude below the entry count: one 8-byte read-back pays for itself)
     KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 8, hipMemcpyDeviceToHost, st));
     KSP_HIP(hipStreamSynchronize(st));
     const u64 K = std::max<u64>(1, e->h_scal[1]);
-    u32* mmsz = flag;                      // flags are dead now
+    u32* mmsz = flag;                      // (VA is free: the head flags are computed on the fly)
     u32* mmoff = (u32*)KA;                 // rk2 is dead after k_emit_keys
     hipLaunchKernelGGL(k_bigflag, dim3(grid_for(K, bs)), dim3(bs), 0, st, estart, scal, mmsz, K);
     tb = 0;
