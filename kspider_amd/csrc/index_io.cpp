@@ -110,36 +110,60 @@ int try_single(const FileBuf& f, size_t slot_bytes, Layout lay, Fn fn) {
 
 }  // namespace
 
+// Position just behind the raw table at `pos` from its header alone (no look at control bytes or slots).
+static bool skip_table(const std::vector<unsigned char>& b, size_t& pos, size_t slot_bytes, Layout lay) {
+    if (pos + 8 > b.size()) return false;
+    uint64_t size, cap;
+    std::memcpy(&size, &b[pos], 8);
+    if (size == 0 && lay.trailer) { pos += 8; return true; }
+    if (pos + 16 > b.size()) return false;
+    std::memcpy(&cap, &b[pos + 8], 8);
+    size_t p = pos + 16;
+    if (size == 0) { pos = p; return true; }
+    if (((cap + 1) & cap) != 0 || size > cap || cap > (1ull << 40)) return false;
+    const size_t bytes = (size_t)cap + lay.kwidth + 1 + slot_bytes * (size_t)cap + (lay.trailer ? 8 : 0);
+    if (p + bytes < p || p + bytes > b.size()) return false;
+    pos = p + bytes;
+    return true;
+}
+
 void load_index(const std::string& prefix, IndexData& out) {
     FileBuf fk(prefix + "_groupID_to_kmerCount.bin");
     FileBuf fc(prefix + "_color_count.bin");
     FileBuf fs(prefix + "_color_to_sources.bin");
 
-    // the three files come from one phmap build: pick the layout that parses all of them
+    // The three files come from one phmap build: pick the layout under which all of them parse.  The
+    // nested file is walked header by header to its end (table positions), and a prefix of its tables is
+    // checked in full (control bytes, cloned bytes); every table is checked in full again when it is read.
     int best = -1, best_score = 0;
+    std::vector<size_t> best_pos;
     for (int li = 0; li < 4; ++li) {
         auto nop = [](const unsigned char*) {};
         int s1 = try_single(fk, 8, kLayouts[li], nop);
         int s2 = try_single(fc, 16, kLayouts[li], nop);
         if (!s1 || !s2) continue;
-        // nested file
         size_t pos = 0;
         int clone = 0;
         bool ok = fs.b.size() >= 8;
         uint64_t C = 0;
+        std::vector<size_t> tpos;
         if (ok) {
             std::memcpy(&C, fs.b.data(), 8);
             pos = 8;
+            if (C > fs.b.size()) ok = false;
+            if (ok) tpos.reserve((size_t)C + 1);
             for (uint64_t c = 0; ok && c < C; ++c) {
                 if (pos + 8 > fs.b.size()) { ok = false; break; }
+                tpos.push_back(pos);
                 pos += 8;
-                ok = parse_table(fs.b, pos, 4, kLayouts[li], &clone, nop);
+                if (c < 4096) ok = parse_table(fs.b, pos, 4, kLayouts[li], &clone, nop);
+                else ok = skip_table(fs.b, pos, 4, kLayouts[li]);
             }
             ok = ok && pos == fs.b.size();
         }
         if (!ok) continue;
         int score = 1 + s1 + s2 + (clone > 0 ? 2 : 0) + (kLayouts[li].kwidth == 16 ? 1 : 0);   // clone bytes decide ties
-        if (score > best_score) { best_score = score; best = li; }
+        if (score > best_score) { best_score = score; best = li; best_pos.swap(tpos); }
     }
     if (best < 0)
         throw std::runtime_error("kspider_amd: " + prefix +
@@ -158,37 +182,80 @@ void load_index(const std::string& prefix, IndexData& out) {
     });
     if (out.kmer_slots.empty())   // assert(groupID_to_kmerCount.size()) src/pairwise.cpp:170
         throw std::runtime_error("kspider_amd: " + fk.path + " holds no groups");
-    try_single(fc, 16, lay, [&](const unsigned char* s) {
-        uint64_t k, v;
-        std::memcpy(&k, s, 8);
-        std::memcpy(&v, s + 8, 8);
-        out.colors_count[(uint32_t)k] = (uint32_t)v;   // insert_or_assign, both narrowed (:119)
-    });
+    {   // colour -> count, insert_or_assign with both sides narrowed (:119)
+        std::vector<std::pair<uint32_t, uint32_t>> kv;
+        try_single(fc, 16, lay, [&](const unsigned char* s) {
+            uint64_t k, v;
+            std::memcpy(&k, s, 8);
+            std::memcpy(&v, s + 8, 8);
+            kv.emplace_back((uint32_t)k, (uint32_t)v);
+        });
+        uint32_t mx = 0;
+        for (auto& e : kv) mx = std::max(mx, e.first);
+        auto& ct = out.colors_count;
+        if (!kv.empty() && (uint64_t)mx < 64ull * kv.size() + (1u << 20)) {
+            ct.direct.assign((size_t)mx + 1, 0);
+            ct.present.assign((size_t)mx + 1, 0);
+            for (auto& e : kv) {
+                ct.n += ct.present[e.first] ? 0 : 1;
+                ct.present[e.first] = 1;
+                ct.direct[e.first] = e.second;   // later slot wins, as insert_or_assign does
+            }
+        } else {
+            for (auto& e : kv) ct.sparse[e.first] = e.second;
+            ct.n = ct.sparse.size();
+        }
+    }
     if (out.colors_count.empty())  // assert(tmpMap.size()) src/pairwise.cpp:117
         throw std::runtime_error("kspider_amd: " + fc.path + " holds no colours");
     {
-        size_t pos = 8;
-        uint64_t C;
-        std::memcpy(&C, fs.b.data(), 8);
-        std::unordered_map<uint32_t, size_t> where;
-        out.colors.reserve((size_t)C);
-        for (uint64_t c = 0; c < C; ++c) {
-            uint64_t k;
-            std::memcpy(&k, &fs.b[pos], 8);
-            pos += 8;
-            std::vector<uint32_t> v;
-            parse_table(fs.b, pos, 4, lay, nullptr, [&](const unsigned char* s) {
-                uint32_t x;
-                std::memcpy(&x, s, 4);
-                v.push_back(x);
-            });
-            const uint32_t k32 = (uint32_t)k;   // narrowing of src/pairwise.cpp:103,109
-            auto it = where.find(k32);
-            if (it == where.end()) {
-                where.emplace(k32, out.colors.size());
-                out.colors.emplace_back(k32, std::move(v));
-            } else {
-                out.colors[it->second].second = std::move(v);
+        const size_t C = best_pos.size();
+        std::vector<std::pair<uint64_t, std::vector<uint32_t>>> raw(C);
+        std::vector<int> bad(1, 0);
+        unsigned nt = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        if (C < 4096) nt = 1;
+        auto work = [&](size_t c0, size_t c1) {
+            for (size_t c = c0; c < c1; ++c) {
+                size_t pos = best_pos[c];
+                uint64_t k;
+                std::memcpy(&k, &fs.b[pos], 8);
+                pos += 8;
+                uint64_t size = 0;
+                std::memcpy(&size, &fs.b[pos], 8);
+                auto& v = raw[c].second;
+                v.reserve((size_t)std::min<uint64_t>(size, 1u << 24));
+                raw[c].first = k;
+                if (!parse_table(fs.b, pos, 4, lay, nullptr, [&](const unsigned char* s) {
+                        uint32_t x;
+                        std::memcpy(&x, s, 4);
+                        v.push_back(x);
+                    }))
+                    bad[0] = 1;
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t) th.emplace_back(work, C * t / nt, C * (t + 1) / nt);
+        for (auto& t : th) t.join();
+        if (bad[0]) throw std::runtime_error("kspider_amd: " + fs.path + " holds a malformed source table");
+        // narrowing of src/pairwise.cpp:103,109 + insert_or_assign: a later colour with the same 32-bit id
+        // replaces the sources of the earlier one (first-insertion order is kept).  Ids below 2^32 are the
+        // map's own distinct keys, so the bookkeeping is only needed when some id is wider.
+        bool wide = false;
+        for (auto& r : raw) wide = wide || (r.first >> 32) != 0;
+        out.colors.reserve(C);
+        if (!wide) {
+            for (auto& r : raw) out.colors.emplace_back((uint32_t)r.first, std::move(r.second));
+        } else {
+            std::unordered_map<uint32_t, size_t> where;
+            for (auto& r : raw) {
+                const uint32_t k32 = (uint32_t)r.first;
+                auto it = where.find(k32);
+                if (it == where.end()) {
+                    where.emplace(k32, out.colors.size());
+                    out.colors.emplace_back(k32, std::move(r.second));
+                } else {
+                    out.colors[it->second].second = std::move(r.second);
+                }
             }
         }
     }

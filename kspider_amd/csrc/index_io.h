@@ -14,8 +14,27 @@ struct IndexData {
     // colour -> sources after the reference's uint32 narrowing + insert_or_assign
     // (src/pairwise.cpp:103,109), in first-insertion (file) order
     std::vector<std::pair<uint32_t, std::vector<uint32_t>>> colors;
-    // colour -> #k-mers, both narrowed to uint32 (src/pairwise.cpp:119)
-    std::unordered_map<uint32_t, uint32_t> colors_count;
+    // colour -> #k-mers, both narrowed to uint32 (src/pairwise.cpp:119): a direct table when the ids are
+    // small (the usual case: colour ids are handed out consecutively), a hash map otherwise
+    struct CountTable {
+        std::vector<uint32_t> direct;      // value per id
+        std::vector<uint8_t> present;      // 1 where the id exists
+        std::unordered_map<uint32_t, uint32_t> sparse;
+        size_t n = 0;
+        bool find(uint32_t k, uint32_t& v) const {
+            if (!direct.empty()) {
+                if (k >= direct.size() || !present[k]) return false;
+                v = direct[k];
+                return true;
+            }
+            auto it = sparse.find(k);
+            if (it == sparse.end()) return false;
+            v = it->second;
+            return true;
+        }
+        size_t size() const { return n; }
+        bool empty() const { return n == 0; }
+    } colors_count;
     // groupID -> k-mer count in table slot order (iteration order of src/pairwise.cpp:175)
     std::vector<std::pair<uint32_t, uint32_t>> kmer_slots;
     int kwidth = 16;       // detected phmap Group::kWidth

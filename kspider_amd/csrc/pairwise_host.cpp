@@ -83,8 +83,8 @@ int run_pairwise(const std::string& prefix, int user_threads) {
     }
     for (size_t ci = 0; ci < ix.colors.size(); ++ci) {
         auto& c = ix.colors[ci];
-        auto it = ix.colors_count.find(c.first);   // colorsCount[item.first] (:221): 0 when absent
-        const uint32_t w = it == ix.colors_count.end() ? 0 : it->second;
+        uint32_t w = 0;
+        if (!ix.colors_count.find(c.first, w)) w = 0;   // colorsCount[item.first] (:221): 0 when absent
         if (c.second.size() < 2) continue;          // a colour with one source produces no pair
         if (w == 0) {
             // the reference still creates the pair entries (with += 0): remember them
