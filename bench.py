@@ -132,6 +132,7 @@ def main():
     total_pairs = n * (n - 1) // 2
 
     keys_d = torch.from_numpy(sk.keys.view(np.int64)).to(dev)
+    key_bits = max(1, int(sk.keys.max()).bit_length()) if sk.keys.size else 1   # the sketcher knows its hash range
     stream = torch.cuda.current_stream(dev)
     eng = engine.Engine(local_rank)
     sharded = world > 1 and os.environ.get("KSP_BENCH_REPLICATED_BUILD") != "1"
@@ -140,7 +141,7 @@ def main():
     if sharded:
         kdist.build_blocks_sharded(eng, keys_d.data_ptr(), sk.offsets, world, rank, dev, stream=stream.cuda_stream)
     else:
-        eng.build_blocks(keys_d.data_ptr(), sk.offsets, stream=stream.cuda_stream)
+        eng.build_blocks(keys_d.data_ptr(), sk.offsets, key_bits=key_bits, stream=stream.cuda_stream)
     cuts = eng.balanced_cuts(world)
     t0, t1 = cuts[rank], cuts[rank + 1]
     cap = int(min(eng.edge_bound(t0, t1), 1 << 27)) + 1
@@ -160,7 +161,7 @@ def main():
             stats["xchg_bytes"] = kdist.build_blocks_sharded(eng, keys_d.data_ptr(), sk.offsets, world, rank, dev,
                                                              stream=stream.cuda_stream)
         else:
-            eng.build_blocks(keys_d.data_ptr(), sk.offsets, stream=stream.cuda_stream)
+            eng.build_blocks(keys_d.data_ptr(), sk.offsets, key_bits=key_bits, stream=stream.cuda_stream)
         buf = step_no[0] & 1
         step_no[0] += 1
         if copied[buf] is not None:
