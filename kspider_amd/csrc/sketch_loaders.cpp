@@ -22,6 +22,10 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <exception>
+#include <thread>
+#include <mutex>
+#include <atomic>
 #include <cctype>
 #include <cerrno>
 #include <chrono>
@@ -39,6 +43,29 @@
 #include "index_io.h"
 
 namespace {
+
+// fn(i) for i in [0, n) on up to `threads` host threads; the first exception is rethrown on the caller
+template <class Fn>
+void parallel_for(size_t n, int threads, Fn fn) {
+    const unsigned nt = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::max(1, threads), n, 64}));
+    if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<size_t> next{0};
+    std::exception_ptr err;
+    std::mutex mu;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&]() {
+            try {
+                for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(mu);
+                if (!err) err = std::current_exception();
+            }
+        });
+    for (auto& t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}
+
 
 std::vector<std::string> glob_dir(const std::string& dir) {
     glob_t g;
@@ -274,18 +301,25 @@ extern "C" int kspider_pairwise_sigs(const char* sigs_dir, int kSize, const char
             if (ext == "sig") sig_files.push_back(f);   // pass 2 of the reference reads ".sig" only
         }
         if (names.empty()) throw std::runtime_error("kspider_amd: no .sig/.gz files in " + dir);
-        std::unordered_map<uint32_t, Source> by_id;
-        for (auto& f : sig_files) {
+        // files are read, parsed and sorted by `user_threads` host threads; the reference's sequential
+        // semantics (a later file of the same group replaces the earlier one) are applied in file order
+        std::vector<Source> parsed(sig_files.size());
+        std::vector<char> has(sig_files.size(), 0);
+        parallel_for(sig_files.size(), user_threads, [&](size_t i) {
+            const std::string& f = sig_files[i];
             std::vector<uint64_t> mins;
-            if (!parse_sig(f, read_maybe_gz(f), kSize, mins)) continue;   // no signature with that ksize
-            Source s;
-            s.id = id_of[stem_of(f)];
+            if (!parse_sig(f, read_maybe_gz(f), kSize, mins)) return;   // no signature with that ksize
+            Source& s = parsed[i];
+            s.id = id_of.at(stem_of(f));
             s.kmers = (uint32_t)mins.size();
             std::sort(mins.begin(), mins.end());
             mins.erase(std::unique(mins.begin(), mins.end()), mins.end());
             s.run.swap(mins);
-            by_id[s.id] = std::move(s);   // a later file of the same group replaces the earlier one
-        }
+            has[i] = 1;
+        });
+        std::unordered_map<uint32_t, Source> by_id;
+        for (size_t i = 0; i < sig_files.size(); ++i)
+            if (has[i]) by_id[parsed[i].id] = std::move(parsed[i]);
         if (by_id.empty()) throw std::runtime_error("kspider_amd: no signature with ksize " + std::to_string(kSize));
         std::vector<Source> src;
         for (auto& kv : by_id) src.push_back(std::move(kv.second));
@@ -301,6 +335,7 @@ extern "C" int kspider_pairwise_bins(const char* bins_dir, const char* out_prefi
         const std::string prefix = (out_prefix && *out_prefix) ? out_prefix : default_prefix(dir);
         std::vector<std::pair<uint32_t, std::string>> names;
         std::vector<Source> src;
+        std::vector<std::string> files;
         std::unordered_map<std::string, uint32_t> seen;
         uint32_t next_id = 1;
         for (auto& f : glob_dir(dir)) {
@@ -311,12 +346,16 @@ extern "C" int kspider_pairwise_bins(const char* bins_dir, const char* out_prefi
             names.emplace_back(next_id, name);
             Source s;
             s.id = next_id++;
-            ksp::load_u64_set(f, s.run);
+            src.push_back(std::move(s));
+            files.push_back(f);
+        }
+        parallel_for(files.size(), user_threads, [&](size_t i) {
+            Source& s = src[i];
+            ksp::load_u64_set(files[i], s.run);
             s.kmers = (uint32_t)s.run.size();
             std::sort(s.run.begin(), s.run.end());
             s.run.erase(std::unique(s.run.begin(), s.run.end()), s.run.end());
-            src.push_back(std::move(s));
-        }
+        });
         if (src.empty()) throw std::runtime_error("kspider_amd: no .bin files in " + dir);
         return run_sources(prefix, names, src, user_threads < 1 ? 1 : user_threads);
     });
