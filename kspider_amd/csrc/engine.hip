@@ -126,12 +126,14 @@ __global__ void k_label(const u32* __restrict__ rk, const V* __restrict__ vals, 
 // rank, and per source the bound of its pair counters (k-mer count / weight sum).
 template <class V, bool W>
 __global__ void k_post_expand(const u32* __restrict__ koff, const u32* __restrict__ src, const u32* __restrict__ kw,
-                              V* __restrict__ vals, u32* __restrict__ rk, u32* __restrict__ src_bound, u32 n_keys) {
+                              V* __restrict__ vals, u32* __restrict__ rk, u32* __restrict__ src_bound, u32 n_keys,
+                              u32 n_sources, u32* __restrict__ bad) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_keys) return;
     const u32 w = W ? kw[r] : 1u;
     for (u32 e = koff[r]; e < koff[r + 1]; ++e) {
-        const u32 s = src[e];
+        u32 s = src[e];
+        if (s >= n_sources) { *bad = 1; s = 0; }   // reported as KSP_E_ARG by the caller; keep the stores in bounds
         const u32 tag = ((s / TB) << 8) | (s % TB);
         vals[e] = W ? (V)(((u64)w << 32) | tag) : (V)tag;
         rk[e] = r;
@@ -1711,8 +1713,9 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         KSP_HIP(hipMemsetAsync(e->blk_max.p, 0, ((size_t)nb + 1) * 4, st));
         KSP_HIP(hipMemsetAsync(sbound, 0, (size_t)N * 4, st));
         const u32 nk = e->post_nkeys;
+        KSP_HIP(hipMemsetAsync(scal + 4, 0, 8, st));
         hipLaunchKernelGGL((k_post_expand<V, W>), dim3(grid_for(nk, bs)), dim3(bs), 0, st, e->post_off, e->post_src,
-                           e->post_w, VA, rank1, sbound, nk);
+                           e->post_w, VA, rank1, sbound, nk, N, (u32*)(scal + 4));
         {   // U = number of keys (what the prune scan reports on the sketch path)
             e->h_scal[2] = nk;
             KSP_HIP(hipMemcpyAsync(scal + 2, e->h_scal + 2, 8, hipMemcpyHostToDevice, st));
@@ -2259,6 +2262,7 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
     if (rc) return rc;
     KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 64, hipMemcpyDeviceToHost, st));
     KSP_HIP(hipStreamSynchronize(st));
+    if ((u32)e->h_scal[4]) { set_error("build_postings: a source index is >= n_sources"); return KSP_E_ARG; }
     if (e->n_kept) {
         e->h_scal_words = e->h_scal[1];
         e->h_scal_keys = e->h_scal[2];

@@ -217,6 +217,14 @@ class Engine:
         _check(lib().ksp_engine_build_blocks(self._h, d_keys_ptr or None, d_weights_ptr or None,
                                              h_offsets.ctypes.data, h_offsets.size - 1, key_bits, stream or None))
 
+    def build_postings(self, h_key_off: np.ndarray, d_sources_ptr: int, d_key_weights_ptr: int, n_sources: int,
+                       stream: int = 0):
+        """Stage 1 from an inverted index: key k is held by d_sources[key_off[k]:key_off[k+1]] (device uint32)."""
+        h_key_off = np.ascontiguousarray(h_key_off, dtype=np.uint64)
+        self._off = h_key_off
+        _check(lib().ksp_engine_build_postings(self._h, h_key_off.ctypes.data, d_sources_ptr or None,
+                                               d_key_weights_ptr or None, h_key_off.size - 1, n_sources, stream or None))
+
     # ---- key-range sharded stage 1 (multi-GPU) ------------------------------------------------
     def build_slice(self, d_keys_ptr: int, h_offsets: np.ndarray, part: int, nparts: int, d_weights_ptr: int = 0,
                     key_bits: int = 0, stream: int = 0):

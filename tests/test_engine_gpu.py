@@ -199,3 +199,13 @@ def test_postings_input_equals_sketch_input(oracle_lib):
     # no key at all
     e0, _ = engine.pairwise_postings_host(np.zeros(1, dtype=np.uint64), np.zeros(0, dtype=np.uint32), None, n)
     assert len(e0) == 0
+
+
+def test_postings_rejects_bad_source_index():
+    dsrc = engine.DeviceBuffer.from_numpy(np.array([0, 1, 2, 7], dtype=np.uint32))   # 7 >= n_sources
+    e = engine.Engine(0)
+    with pytest.raises(engine.KspError) as ei:
+        e.build_postings(np.array([0, 2, 4], dtype=np.uint64), dsrc.ptr.value, 0, 5)
+    assert ei.value.code == engine.KSP_E_ARG
+    with pytest.raises(engine.KspError):
+        e.build_postings(np.array([0, 1, 4], dtype=np.uint64), dsrc.ptr.value, 0, 8)   # a key with one holder
