@@ -1,0 +1,564 @@
+// Stage 1 of the engine: device kernels that turn the sketches (sorted uint64 runs) — or an inverted
+// index — into per-block posting lists, the source order and the join's tile bitmap.
+// Included by engine.hip inside namespace ksp (one translation unit: the kernels are templates over the
+// tag type and share the constants defined there).  Host orchestration: build_impl in engine.hip.
+#pragma once
+// ------------------------------------------------------------------------------------
+// stage 1 kernels
+// ------------------------------------------------------------------------------------
+
+// One workgroup per source: tag each entry with (block << 8 | local id) [and weight].
+// Weighted mode also records the source's weight sum (the bound of any pair counter that source
+// takes part in; unweighted: k_src_size).
+template <bool W>
+__global__ void k_tag(const u64* __restrict__ off, const u32* __restrict__ wts, u32* __restrict__ val32,
+                      u64* __restrict__ val64, u32* __restrict__ src_bound) {
+    __shared__ unsigned long long acc;
+    const u32 s = blockIdx.x;
+    const u64 b = off[s], e = off[s + 1];
+    const u32 tag = ((s / TB) << 8) | (s % TB);
+    if (W) { if (threadIdx.x == 0) acc = 0; __syncthreads(); }
+    unsigned long long part = 0;
+    for (u64 i = b + threadIdx.x; i < e; i += blockDim.x) {
+        if (W) { const u32 w = wts[i]; part += w; val64[i] = ((u64)w << 32) | tag; }
+        else val32[i] = tag;
+    }
+    if (W) {
+        if (part) atomicAdd(&acc, part);
+        __syncthreads();
+        if (threadIdx.x == 0) src_bound[s] = (u32)(acc > 0xFFFFFFFFull ? 0xFFFFFFFFull : acc);
+    }
+}
+__global__ void k_src_size(const u64* __restrict__ off, u32* __restrict__ src_bound, u32 n_sources) {
+    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_sources) { const u64 c = off[s + 1] - off[s]; src_bound[s] = (u32)(c > 0xFFFFFFFFull ? 0xFFFFFFFFull : c); }
+}
+
+// ---- source reordering ---------------------------------------------------------------------
+// Sources that share keys are moved next to each other before they are cut into blocks: a source's
+// label is the smallest source id among the holders of any of its shared keys (one round of
+// min-label propagation over the key groups), and the sources are ordered by (label, id).  Related
+// sources then meet inside a block — their common keys collapse into one list word with a
+// multi-source posting — and most block pairs share no key at all, which the join skips.  The
+// engine works on the new indices; k_join maps them back when it emits an edge.
+__global__ void k_iota(u32* __restrict__ p, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+__device__ inline u32 src_of_tag(u32 t) { return (t >> 8) * TB + (t & 0xFFu); }
+template <class V>
+__global__ void k_label(const u32* __restrict__ rk, const V* __restrict__ vals, const u32* __restrict__ first,
+                        u32* __restrict__ label, const u32 skip, u64 n) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || (rk[e] & skip)) return;
+    const u32 s = src_of_tag((u32)vals[e]);
+    const u32 f = src_of_tag((u32)vals[first[rk[e]]]);   // entries of a key are in ascending source order
+    if (f < label[s]) atomicMin(&label[s], f);
+}
+// Postings input (an inverted index: per key its holders, e.g. the reference's colour -> sources map):
+// the state stage 1 reaches after sorting and pruning, written directly — entry tags, the key index as
+// rank, and per source the bound of its pair counters (k-mer count / weight sum).
+template <class V, bool W>
+__global__ void k_post_expand(const u32* __restrict__ koff, const u32* __restrict__ src, const u32* __restrict__ kw,
+                              V* __restrict__ vals, u32* __restrict__ rk, u32* __restrict__ src_bound, u32 n_keys,
+                              u32 n_sources, u32* __restrict__ bad) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_keys) return;
+    const u32 w = W ? kw[r] : 1u;
+    for (u32 e = koff[r]; e < koff[r + 1]; ++e) {
+        u32 s = src[e];
+        if (s >= n_sources) { *bad = 1; s = 0; }   // reported as KSP_E_ARG by the caller; keep the stores in bounds
+        const u32 tag = ((s / TB) << 8) | (s % TB);
+        vals[e] = W ? (V)(((u64)w << 32) | tag) : (V)tag;
+        rk[e] = r;
+        if (w) atomicAdd(&src_bound[s], w);   // (the caller guarantees sums below 2^32)
+    }
+}
+// order[i] = i-th source in (label, id) order  ->  newidx[order[i]] = i; order itself is the inverse map
+__global__ void k_perm(const u32* __restrict__ order, u32* __restrict__ newidx, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) newidx[order[i]] = i;
+}
+template <class V>
+__global__ void k_retag(V* __restrict__ vals, const u32* __restrict__ newidx, u64 n) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const V v = vals[e];
+    const u32 ni = newidx[src_of_tag((u32)v)];
+    vals[e] = (V)((v & ~(V)0xFFFFFFFFu) | (V)(((ni / TB) << 8) | (ni % TB)));
+}
+// per block (of the new order): the largest per-source bound
+__global__ void k_blk_bound(const u32* __restrict__ src_bound, const u32* __restrict__ newidx, u32* __restrict__ blk_max,
+                            u32 n_sources) {
+    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_sources) atomicMax(&blk_max[newidx[s] / TB], src_bound[s]);
+}
+
+template <class V> __device__ inline u32 tag_of(V v) { return (u32)v; }
+
+// The global sort only looks at the top 32 significant bits of the keys (4 radix passes
+// instead of up to 8).  Entries whose keys agree in those bits are adjacent afterwards;
+// almost always they are copies of ONE key (the same hash in several sources).  Where two or
+// more distinct keys share the bits, this kernel orders that short run by the full key so
+// that equal keys become adjacent (ranks only have to be consistent, not numerically
+// ordered).  Runs longer than MAX_FIX raise *overflow and the caller falls back to a
+// full-width sort.
+constexpr u32 MAX_FIX = 2048;
+// pass 1 (streaming): positions where two neighbours share the sorted prefix but differ as
+// full keys go to a work list (rare: ~D^2 / 2^33 of D distinct keys).
+__global__ __launch_bounds__(1024) void k_find_mixed(const u64* __restrict__ keys, u64 n, int shift,
+                                                     u32* __restrict__ list, u32* __restrict__ count, u32 cap,
+                                                     u32* __restrict__ overflow) {
+    // 4096 entries per workgroup; hits are compacted in LDS so that the global counter sees
+    // one atomic per workgroup (a single word saturates at ~88 atomics/us on this chip)
+    __shared__ u32 local[4096];
+    __shared__ u32 nlocal, base;
+    if (threadIdx.x == 0) nlocal = 0;
+    __syncthreads();
+    const u64 e0 = (u64)blockIdx.x * 4096 + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const u64 e = e0 + (u64)r * 1024;
+        if (e > 0 && e < n) {
+            const u64 a = keys[e - 1], b = keys[e];
+            if (a != b && (a >> shift) == (b >> shift)) local[atomicAdd(&nlocal, 1u)] = (u32)e;
+        }
+    }
+    __syncthreads();
+    const u32 m = nlocal;
+    if (m == 0) return;
+    if (threadIdx.x == 0) base = atomicAdd(count, m);
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < m; i += 1024) {
+        if (base + i < cap) list[base + i] = local[i];
+        else *overflow = 1;
+    }
+}
+// pass 2 (work list, read-only): keep only the first listed position of every run — the one
+// with no differing neighbour pair between the run's start and itself; list[i] |= DROP otherwise.
+constexpr u32 DROP = 0x80000000u;
+__global__ void k_mark_first(const u64* __restrict__ keys, int shift, u32* __restrict__ list,
+                             const u32* __restrict__ count, u32 cap, u32* __restrict__ overflow) {
+    const u32 m = min(*count, cap);
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+        const u64 p = list[i];
+        const u64 h0 = keys[p] >> shift;
+        bool first = true;
+        for (u64 s = p - 1; s > 0 && (keys[s - 1] >> shift) == h0; --s) {
+            if (keys[s - 1] != keys[s]) { first = false; break; }
+            if (p - s > MAX_FIX) { *overflow = 1; first = false; break; }
+        }
+        if (!first) list[i] = (u32)p | DROP;
+    }
+}
+// pass 3: one wavefront per kept position orders its run by the full key (runs are disjoint).
+// A run (two or three keys, each held by up to a few hundred sources) is ranked through LDS: every
+// entry counts the entries that must precede it (smaller key, or equal key and earlier position:
+// stable, so sources stay ascending inside a key) and is scattered to that place.  Runs longer than
+// FIX_WAVE entries fall back to a serial insertion sort by lane 0.
+constexpr u32 FIX_WAVE = 512;
+template <class V>
+__global__ __launch_bounds__(256) void k_fix_runs(u64* __restrict__ keys, V* __restrict__ vals, u64 n, int shift,
+                                                  const u32* __restrict__ list, const u32* __restrict__ count, u32 cap,
+                                                  u32* __restrict__ overflow) {
+    __shared__ u64 sk[4][FIX_WAVE];
+    __shared__ V sv[4][FIX_WAVE];
+    const u32 m = min(*count, cap);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (u32 i = wave; i < m; i += nwaves) {
+        const u32 li = list[i];
+        if (li & DROP) continue;
+        const u64 p = li;
+        const u64 h0 = keys[p] >> shift;
+        // run start: walk back 64 entries at a time
+        u64 s = p;
+        bool open = true;
+        while (open && p - s < FIX_WAVE) {
+            const bool in = s >= (u64)(64 - lane) && (keys[s - 64 + lane] >> shift) == h0;   // entry s - 64 + lane
+            const unsigned long long mb = __ballot(in);
+            const int back = mb == ~0ull ? 64 : __builtin_clzll(~mb);   // run entries right before s
+            s -= (u64)back;
+            open = back == 64;
+        }
+        u64 end = p + 1;
+        open = true;
+        while (open && end - s <= FIX_WAVE) {
+            const u64 q = end + (u64)lane;
+            const bool in = q < n && (keys[q] >> shift) == h0;
+            const unsigned long long mf = __ballot(in);
+            const int fwd = mf == ~0ull ? 64 : __builtin_ctzll(~mf);
+            end += (u64)fwd;
+            open = fwd == 64;
+        }
+        const u32 len = (u32)(end - s);
+        if (len <= FIX_WAVE) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (u32 j = lane; j < len; j += 64) { sk[wv][j] = keys[s + j]; sv[wv][j] = vals[s + j]; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (u32 j = lane; j < len; j += 64) {
+                const u64 k = sk[wv][j];
+                u32 before = 0;
+                for (u32 t = 0; t < len; ++t) {
+                    const u64 kt = sk[wv][t];
+                    before += (kt < k || (kt == k && t < j)) ? 1u : 0u;
+                }
+                keys[s + before] = k;
+                vals[s + before] = sv[wv][j];
+            }
+            continue;
+        }
+        if (lane != 0) continue;
+        // very long run: serial (rare)
+        u64 s0 = p;
+        while (s0 > 0 && (keys[s0 - 1] >> shift) == h0) --s0;   // <= MAX_FIX steps (checked by k_mark_first)
+        u64 e1 = p + 1;
+        while (e1 < n && (keys[e1] >> shift) == h0 && e1 - s0 <= MAX_FIX) ++e1;
+        if (e1 - s0 > MAX_FIX) { *overflow = 1; continue; }
+        for (u64 a = s0 + 1; a < e1; ++a) {
+            const u64 k = keys[a];
+            const V v = vals[a];
+            u64 j = a;
+            while (j > s0 && keys[j - 1] > k) { keys[j] = keys[j - 1]; vals[j] = vals[j - 1]; --j; }
+            keys[j] = k;
+            vals[j] = v;
+        }
+    }
+}
+
+// Singleton pruning + dense ranks, after the global sort by key.  A key held by exactly one
+// source (a run of length 1) cannot contribute to any pair: its entry is dropped, which
+// shortens every block list (less to stream and search in the join) and all later passes.
+// The kept keys get dense ranks 0..U-1 — an exact, order-preserving 32-bit stand-in for the
+// 64-bit hash.  One scan over packed counters: low word = kept entries, high word = kept keys.
+struct PruneFn {
+    const u64* keys;
+    u64 n;
+    __device__ u64 operator()(u64 e) const {
+        const u64 k = keys[e];
+        const bool head = e == 0 || keys[e - 1] != k;
+        const bool last = e + 1 == n || keys[e + 1] != k;
+        const bool single = head && last;
+        return (single ? 0ull : 1ull) | ((u64)(head && !single) << 32);
+    }
+};
+// Output "iterator" of the prune scan: instead of storing the packed prefix sums (and reading them back
+// in a second pass), the scan's store of element e moves entry e to its place among the kept entries.
+template <class V>
+struct PruneScatterIt {
+    using iterator_category = std::random_access_iterator_tag;
+    using value_type = u64;
+    using difference_type = std::ptrdiff_t;
+    using pointer = void;
+    struct Ctx {
+        const u64* keys;
+        const V* vals;
+        V* vals2;
+        u32* rank2;
+        u32* first;
+        u64* scal;
+        u64 n;
+    };
+    struct Ref {
+        Ctx c;
+        u64 e;
+        __device__ const Ref& operator=(const u64 cur) const {
+            const u64 f = PruneFn{c.keys, c.n}(e);
+            const u32 lo = (u32)cur, hi = (u32)(cur >> 32);
+            if (f & 1ull) {   // kept entry
+                c.vals2[lo - 1] = c.vals[e];
+                c.rank2[lo - 1] = hi - 1u;
+                if (f >> 32) c.first[hi - 1u] = lo - 1;   // first kept entry of its key
+            }
+            if (e == c.n - 1) {
+                c.scal[6] = lo;   // kept entries
+                c.scal[2] = hi;   // kept distinct keys (U)
+            }
+            return *this;
+        }
+    };
+    using reference = Ref;
+    Ctx c;
+    u64 base;
+    __host__ __device__ PruneScatterIt operator+(const std::ptrdiff_t d) const { return PruneScatterIt{c, base + (u64)d}; }
+    __host__ __device__ PruneScatterIt& operator+=(const std::ptrdiff_t d) { base += (u64)d; return *this; }
+    __device__ Ref operator[](const std::ptrdiff_t i) const { return Ref{c, base + (u64)i}; }
+    __device__ Ref operator*() const { return Ref{c, base}; }
+};
+
+// 1 when entry e opens a new (block, rank) group; evaluated on the fly by the scan and the passes after it
+// (two neighbouring loads of two arrays) instead of being written out by a pass of its own
+template <class V>
+struct HeadFn {
+    const u32* rk;
+    const V* vals;
+    __device__ u32 operator()(u64 e) const {
+        if (e == 0) return 1u;
+        return ((tag_of(vals[e]) >> 8) != (tag_of(vals[e - 1]) >> 8)) || (rk[e] != rk[e - 1]) ? 1u : 0u;
+    }
+};
+
+// scal[1] = Ktot (distinct (block, key) groups), estart[Ktot] = n.
+template <class V>
+__global__ void k_ktot(const HeadFn<V> head, const u32* __restrict__ didx, u32* __restrict__ estart,
+                       u64* __restrict__ scal, u64 n) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        u32 k = didx[n - 1] + head(n - 1);
+        estart[k] = (u32)n;
+        scal[1] = k;
+    }
+}
+
+// raw (unpadded) first distinct-key index of each block: entries are sorted by block, so the
+// first entry of block b is found by bisection over the tags.
+template <class V>
+__global__ void k_blk_raw(const V* __restrict__ vals, const u32* __restrict__ didx, const u64* __restrict__ scal,
+                          u32* __restrict__ blk_raw, u32 nb, u64 n) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    u64 lo = 0, hi = n;
+    while (lo < hi) {
+        u64 mid = lo + ((hi - lo) >> 1);
+        if ((tag_of(vals[mid]) >> 8) < b) lo = mid + 1; else hi = mid;
+    }
+    blk_raw[b] = (lo < n) ? didx[lo] : (u32)scal[1];
+}
+
+// Padded layout of the block lists: every list starts at a multiple of 4 entries and is
+// followed by >= WIN pad entries (rank PAD = +inf), so that any 16-byte-aligned window of
+// WIN entries that starts inside a list is sorted and never runs into the next list.
+__global__ void k_blk_pos(const u32* __restrict__ blk_raw, u32* __restrict__ blk_pos, u64* __restrict__ scal, u32 nb) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        u32 pos = 0;
+        for (u32 b = 0; b < nb; ++b) {
+            blk_pos[b] = pos;
+            u32 cnt = blk_raw[b + 1] - blk_raw[b];
+            pos = ((pos + cnt + 3u) & ~3u) + WIN;
+        }
+        blk_pos[nb] = pos;
+        scal[3] = pos;
+    }
+}
+
+// tail pads of every block list (+inf ranks): from the end of list b to the start of list b + 1, and
+// 4 windows of slack behind the last list
+__global__ void k_pad(const u32* __restrict__ blk_raw, const u32* __restrict__ blk_pos, u32* __restrict__ brk, u32 nb, u32 padv) {
+    const u32 b = blockIdx.x;
+    const u32 lo = b < nb ? blk_pos[b] + (blk_raw[b + 1] - blk_raw[b]) : blk_pos[nb];
+    const u32 hi = b < nb ? blk_pos[b + 1] : blk_pos[nb] + 4u * WIN;
+    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) brk[i] = padv;
+}
+__global__ void k_fill(u32* __restrict__ p, u32 v, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// distinct ranks of every block (padded layout) + first entry of each group.
+template <class V>
+__global__ void k_emit_keys(const u32* __restrict__ rk, const V* __restrict__ vals, const HeadFn<V> head,
+                            const u32* __restrict__ didx, const u32* __restrict__ blk_raw,
+                            const u32* __restrict__ blk_pos, u32* __restrict__ brk, u32* __restrict__ estart, u64 n) {
+    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    if (head(e)) {
+        u32 d = didx[e], b = tag_of(vals[e]) >> 8;
+        brk[blk_pos[b] + (d - blk_raw[b])] = rk[e];
+        estart[d] = (u32)e;
+    }
+}
+
+__global__ void k_bigflag(const u32* __restrict__ estart, const u64* __restrict__ scal, u32* __restrict__ big,
+                          u64 cap) {
+    u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= cap) return;
+    u32 v = 0;
+    if (d < scal[1]) v = (estart[d + 1] - estart[d]) > INLINE_MAX ? 1u : 0u;
+    big[d] = v;
+}
+
+// Posting word of a distinct key (which of the block's 128 sources hold it):
+//   bits 31..29 = c-1 for c <= 4 sources, whose 7-bit local ids sit in bits 0..27
+//   (ascending, 7 bits each);  bits 31..29 = 7 -> more than 4 sources: bits 0..28 index a
+//   128-bit membership mask in `bigmask`.
+template <class V, bool W>
+__global__ void k_emit_info(const u32* __restrict__ estart, const u32* __restrict__ bigoff,
+                            const u64* __restrict__ scal, const V* __restrict__ vals,
+                            const u32* __restrict__ blk_raw, const u32* __restrict__ blk_pos, u32* __restrict__ info,
+                            uint4* __restrict__ bigmask, u32* __restrict__ bw) {
+    u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= scal[1]) return;
+    u32 b = estart[d], c = estart[d + 1] - b;
+    V v0 = vals[b];
+    u32 blk = tag_of(v0) >> 8;
+    u32 dst = blk_pos[blk] + ((u32)d - blk_raw[blk]);
+    if (W) bw[dst] = (u32)((u64)v0 >> 32);
+    if (c <= INLINE_MAX) {
+        u32 inf = (c - 1) << 29;
+        for (u32 i = 0; i < c; ++i) inf |= (tag_of(vals[b + i]) & 0x7F) << (7 * i);
+        info[dst] = inf;
+    } else {
+        u32 m[4] = {0, 0, 0, 0};
+        for (u32 i = 0; i < c; ++i) {
+            u32 id = tag_of(vals[b + i]) & 0x7F;
+            m[id >> 5] |= 1u << (id & 31);
+        }
+        u32 o = bigoff[d];
+        info[dst] = BIG | o;
+        bigmask[o] = make_uint4(m[0], m[1], m[2], m[3]);
+    }
+}
+
+// Fine cell index: cidx[b][f] = position (padded layout) of the first key of block b whose rank
+// is >= f * ceil(U / ncell)  (f = 0..ncell).  Ranks are dense, so equal rank ranges are equal
+// shares of the distinct keys whatever the distribution of the hash values.
+__global__ void k_cidx(const u32* __restrict__ brk, const u32* __restrict__ blk_raw, const u32* __restrict__ blk_pos,
+                       const u64* __restrict__ scal, u32* __restrict__ cidx, u32 nb, u32 ncell) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (u64)nb * (ncell + 1)) return;
+    u32 b = (u32)(i / (ncell + 1)), f = (u32)(i % (ncell + 1));
+    u32 lo = blk_pos[b], hi = lo + (blk_raw[b + 1] - blk_raw[b]);
+    if (f == ncell) { cidx[i] = hi; return; }
+    u64 step = (scal[2] + ncell - 1) / ncell;
+    u64 v = (u64)f * step;
+    while (lo < hi) {
+        u32 mid = lo + ((hi - lo) >> 1);
+        if ((u64)brk[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    cidx[i] = lo;
+}
+
+__device__ inline u64 tile_row_start_dev(u64 r, u64 nb) { return r * nb - r * (r - 1) / 2; }
+
+// ---- which block pairs share a key, and how much work a diagonal tile is ------------------------
+// (rank, block) of every list word; sorted by rank, the words of one key are adjacent and the
+// block pairs among them are exactly the tiles that have something to count.
+__global__ void k_list_pairs(const u32* __restrict__ brk, const u32* __restrict__ info, const uint4* __restrict__ bigmask,
+                             const u32* __restrict__ blk_raw, const u32* __restrict__ blk_pos, u32* __restrict__ pr,
+                             u32* __restrict__ pb, unsigned long long* __restrict__ work) {
+    // grid (block, share): also sums the pair updates of the block's diagonal tile, C(holders, 2) per key
+    const u32 b = blockIdx.x;
+    const u32 cnt = blk_raw[b + 1] - blk_raw[b], src = blk_pos[b], dst = blk_raw[b];
+    const u32 i0 = (u32)(((u64)cnt * blockIdx.y) / gridDim.y), i1 = (u32)(((u64)cnt * (blockIdx.y + 1)) / gridDim.y);
+    unsigned long long acc = 0, holders = 0;
+    for (u32 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        pr[dst + i] = brk[src + i];
+        pb[dst + i] = b;
+        const u32 inf = info[src + i];
+        u32 c;
+        if (inf >= BIG) { const uint4 m = bigmask[inf & ~BIG]; c = __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w); }
+        else c = (inf >> 29) + 1;
+        acc += (unsigned long long)c * (c - 1) / 2;
+        holders += c;
+    }
+    for (int o = 32; o > 0; o >>= 1) { acc += __shfl_down(acc, o); holders += __shfl_down(holders, o); }
+    if ((threadIdx.x & 63) == 0) {
+        if (acc) atomicAdd(&work[b], acc);
+        if (holders) atomicAdd(&work[gridDim.x], holders);   // slot nb: holders summed over all list words
+    }
+}
+// one byte per tile: plain idempotent stores (a few hundred active tiles take millions of hits —
+// atomics on the same words would serialise in L2)
+__global__ void k_tile_flags(const u32* __restrict__ pr, const u32* __restrict__ pb, u64 n, u32 nb,
+                             unsigned char* __restrict__ flags) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 r = pr[i], I = pb[i];
+    for (u64 j = i + 1; j < n && pr[j] == r; ++j) {   // (stable sort: blocks ascend inside a key)
+        const u64 t = tile_row_start_dev(I, nb) + (pb[j] - I);
+        if (!flags[t]) flags[t] = 1;
+    }
+}
+__global__ void k_pack_flags(const unsigned char* __restrict__ flags, u64 n, u32* __restrict__ bits) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;   // blockDim is a multiple of 64
+    const unsigned long long m = __ballot(t < n && flags[t] != 0);
+    if ((threadIdx.x & 63) == 0) { bits[t >> 5] = (u32)m; bits[(t >> 5) + 1] = (u32)(m >> 32); }
+}
+
+// ---- key-range slices (multi-GPU build) -----------------------------------------------
+// Rank p of G builds the block lists of the keys in its 1/G share of the hash range only
+// (filter -> same pipeline on n/G entries); the slices are exchanged (all-gather) and every
+// rank assembles the full lists: slice p's ranks are shifted by the number of distinct keys
+// of the slices before it, so concatenating the slices of a block in part order is sorted.
+// Every source's run is sorted, so its keys inside [lo, hi] are one contiguous sub-run: two
+// bisections per source instead of a pass over all entries.
+__global__ void k_range_bounds(const u64* __restrict__ keys, const u64* __restrict__ off, u64 lo, u64 hi,
+                               u32* __restrict__ first, u32* __restrict__ cnt, u32 n_sources) {
+    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_sources) return;
+    const u64 b = off[s], e = off[s + 1];
+    u64 l = b, r = e;
+    while (l < r) { u64 m = l + ((r - l) >> 1); if (keys[m] < lo) l = m + 1; else r = m; }
+    const u64 a = l;
+    r = e;
+    while (l < r) { u64 m = l + ((r - l) >> 1); if (keys[m] <= hi) l = m + 1; else r = m; }
+    first[s] = (u32)(a - b);
+    cnt[s] = (u32)(l - a);
+}
+// one workgroup per source: copy its sub-run and tag it (block << 8 | local id [| weight << 32])
+template <class V, bool W>
+__global__ void k_range_copy(const u64* __restrict__ keys, const u32* __restrict__ wts, const u64* __restrict__ off,
+                             const u32* __restrict__ first, const u32* __restrict__ cnt, const u32* __restrict__ fpos,
+                             u64* __restrict__ fkeys, V* __restrict__ ftags) {
+    const u32 s = blockIdx.x;
+    const u64 src = off[s] + first[s];
+    const u32 c = cnt[s], dst = fpos[s];
+    const u32 tag = ((s / TB) << 8) | (s % TB);
+    for (u32 i = threadIdx.x; i < c; i += blockDim.x) {
+        fkeys[dst + i] = keys[src + i];
+        if (W) ftags[dst + i] = (V)(((u64)wts[src + i] << 32) | tag);
+        else ftags[dst + i] = (V)tag;
+    }
+}
+__global__ void k_range_total(const u32* __restrict__ fpos, const u32* __restrict__ cnt, u64* __restrict__ scal, u32 n_sources) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[8] = (u64)fpos[n_sources - 1] + cnt[n_sources - 1];
+}
+// largest key = largest last element of the sorted runs
+__global__ void k_max_last(const u64* __restrict__ keys, const u64* __restrict__ off, unsigned long long* __restrict__ out,
+                           u32 n_sources) {
+    u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (s < n_sources && off[s + 1] > off[s]) v = keys[off[s + 1] - 1];
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned long long)__shfl_down(v, o));
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(out, v);
+}
+
+__global__ void k_nbig(const u32* __restrict__ bigflag, const u32* __restrict__ bigoff, u64* __restrict__ scal) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const u64 k = scal[1];
+        scal[7] = k ? (u64)bigoff[k - 1] + bigflag[k - 1] : 0;
+    }
+}
+// global block counts from the parts' counts (serial: nb x parts is small)
+__global__ void k_asm_counts(const u32* __restrict__ raw_all, u32 stride, u32 nparts, u32 nb, u32* __restrict__ blk_raw) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        u32 acc = 0;
+        for (u32 b = 0; b < nb; ++b) {
+            blk_raw[b] = acc;
+            for (u32 p = 0; p < nparts; ++p) acc += raw_all[(size_t)p * stride + b + 1] - raw_all[(size_t)p * stride + b];
+        }
+        blk_raw[nb] = acc;
+    }
+}
+// one workgroup per (block, part): copy the part's slice of the block into the full list
+template <bool W>
+__global__ void k_asm_copy(const u32* __restrict__ brk_all, const u32* __restrict__ info_all,
+                           const u32* __restrict__ bw_all, size_t lstride, const u32* __restrict__ raw_all,
+                           const u32* __restrict__ pos_all, u32 bstride, const u32* __restrict__ rank_off,
+                           const u32* __restrict__ big_off, const u32* __restrict__ blk_pos, u32* __restrict__ brk,
+                           u32* __restrict__ info, u32* __restrict__ bw) {
+    const u32 b = blockIdx.x, p = blockIdx.y;
+    u32 before = 0;
+    for (u32 q = 0; q < p; ++q) before += raw_all[(size_t)q * bstride + b + 1] - raw_all[(size_t)q * bstride + b];
+    const u32 cnt = raw_all[(size_t)p * bstride + b + 1] - raw_all[(size_t)p * bstride + b];
+    const size_t src = (size_t)p * lstride + pos_all[(size_t)p * bstride + b];
+    const u32 dst = blk_pos[b] + before;
+    const u32 ro = rank_off[p], bo = big_off[p];
+    for (u32 i = threadIdx.x; i < cnt; i += blockDim.x) {
+        brk[dst + i] = brk_all[src + i] + ro;
+        u32 inf = info_all[src + i];
+        if (inf >= BIG) inf = BIG | ((inf & ~BIG) + bo);
+        info[dst + i] = inf;
+        if (W) bw[dst + i] = bw_all[src + i];
+    }
+}
+
