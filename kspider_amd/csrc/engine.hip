@@ -183,6 +183,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     u32* sm = e->smap.as<u32>();
     u32 *label = sm, *iota = sm + NN, *labs = sm + 2 * NN, *order = sm + 3 * NN, *newidx = sm + 4 * NN, *sbound = sm + 5 * NN;
     const bool reorder = e->reorder;
+    u32 label_max = std::max<u32>(256, N / 16);   // holders above which a key is ignored by the label pass
+    if (const char* lm = std::getenv("KSP_DEBUG_LABEL_MAX")) label_max = (u32)std::max(1, std::atoi(lm));
     int bbits = 1;
     while ((1u << bbits) < nb) ++bbits;
     size_t tb = 0;
@@ -206,7 +208,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         }
         if (reorder) {
             const u32 skip = m / std::max<u32>(1, N) >= 512 ? 7u : 0u;
-            hipLaunchKernelGGL((k_label<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, VA, e->post_off, label, skip, m);
+            hipLaunchKernelGGL((k_label<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, VA, e->post_off, label, skip,
+                               label_max, m);
         } else {
             hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
         }
@@ -302,7 +305,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     }
     // singleton pruning + dense ranks of the kept keys (packed counters, one scan):  KA,VB -> R1 (ranks), VA (tags)
     // (the scan's output iterator scatters entry e as soon as its prefix sums are known: no second pass)
-    if ((rc = e->FK.ensure((nw / 2 + 8) * 4))) return rc;
+    if ((rc = e->FK.ensure((nw / 2 + 16) * 4))) return rc;
     u32* first = (u32*)e->FK.p;            // first kept entry of every rank (FK: the slice's input keys are dead after sort 1)
     {
         auto pf = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u64>(0), PruneFn{KA, nw});
@@ -321,7 +324,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         // label = smallest source id among the holders of a source's shared keys
         // (sources with hundreds of shared keys: every 8th key says as much about a source's relatives as all)
         const u32 skip = m / std::max<u32>(1, N) >= 512 ? 7u : 0u;
-        hipLaunchKernelGGL((k_label<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, VA, first, label, skip, m);
+        hipLaunchKernelGGL((k_label<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, VA, first, label, skip,
+                           label_max, m);
     }
     if (phase == 1) return KSP_OK;
     }   // phase != 2

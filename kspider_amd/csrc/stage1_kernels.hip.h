@@ -48,11 +48,15 @@ __global__ void k_iota(u32* __restrict__ p, u32 n) {
 __device__ inline u32 src_of_tag(u32 t) { return (t >> 8) * TB + (t & 0xFFu); }
 template <class V>
 __global__ void k_label(const u32* __restrict__ rk, const V* __restrict__ vals, const u32* __restrict__ first,
-                        u32* __restrict__ label, const u32 skip, u64 n) {
+                        u32* __restrict__ label, const u32 skip, const u32 max_holders, u64 n) {
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n || (rk[e] & skip)) return;
+    const u32 r = rk[e], f0 = first[r];
+    // a key held by very many sources says nothing about who is related to whom — it would only pull
+    // unrelated clusters under one label (first[] has a sentinel: first[U] = number of entries)
+    if (first[r + 1] - f0 > max_holders) return;
     const u32 s = src_of_tag((u32)vals[e]);
-    const u32 f = src_of_tag((u32)vals[first[rk[e]]]);   // entries of a key are in ascending source order
+    const u32 f = src_of_tag((u32)vals[f0]);   // entries of a key are in ascending source order
     if (f < label[s]) atomicMin(&label[s], f);
 }
 // Postings input (an inverted index: per key its holders, e.g. the reference's colour -> sources map):
@@ -273,6 +277,7 @@ struct PruneScatterIt {
             if (e == c.n - 1) {
                 c.scal[6] = lo;   // kept entries
                 c.scal[2] = hi;   // kept distinct keys (U)
+                c.first[hi] = lo; // sentinel: one past the last kept entry
             }
             return *this;
         }
