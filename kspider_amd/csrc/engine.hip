@@ -141,12 +141,12 @@ namespace ksp {
 
 static inline unsigned grid_for(u64 n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
-template <bool W>
+template <class V>
 static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStream_t st, const int phase) {
+    constexpr bool W = std::is_same<V, u64>::value;   // weighted: 64-bit tags carry the key's weight
     // phase 0: the whole of stage 1;  1: up to the source labels (key-range slice, before the labels of all
     // slices are combined);  2: the rest (source order from the final labels, block lists);  3: postings
     // input (ksp_engine_build_postings: sorting and pruning are already done by the caller's inverted index)
-    typedef typename std::conditional<W, u64, u32>::type V;
     const u64 n = e->n_entries;
     const u32 N = e->n_sources, nb = e->nb;
     const u64 lmax = n + (u64)nb * (WIN + 4) + 4 * WIN;   // upper bound of the padded layout (+ read slack)
@@ -230,8 +230,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     }
     const int kbits = e->key_bits;
     if (W || e->nparts == 1)   // (weighted slices still need the per-source weight sums of all entries)
-        hipLaunchKernelGGL((k_tag<W>), dim3(N), dim3(256), 0, st, d_off, d_w, W ? nullptr : (u32*)VA,
-                           W ? (u64*)VA : nullptr, sbound);
+        hipLaunchKernelGGL((k_tag<V, W>), dim3(N), dim3(256), 0, st, d_off, d_w, VA, sbound);
     if (!W) hipLaunchKernelGGL(k_src_size, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_off, sbound, N);
     hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, iota, N);
     hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, N);    // identity until the labels are known
@@ -345,9 +344,10 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     // sort 2: stable by block id (bits [8, 8+bbits) of the tag), payload = rank:  VA,rank1 -> VB,rk2
     u32* rk2 = (u32*)KA;                   // KA (sorted keys) is dead from here on
     tb = 0;
-    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, VA, VB, rank1, rk2, m, 8, 8 + bbits, st));
+    const int bbeg = sizeof(V) == 2 ? 7 : 8;   // the block id inside a compact / canonical tag
+    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, VA, VB, rank1, rk2, m, bbeg, bbeg + bbits, st));
     if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, VA, VB, rank1, rk2, m, 8, 8 + bbits, st));
+    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, VA, VB, rank1, rk2, m, bbeg, bbeg + bbits, st));
     // now: rk2 = ranks sorted by (block, rank); VB = tags in the same order.  KB, VA, R1 are free.
     V* T = VB;
     u32* flag = (u32*)VA;
@@ -385,6 +385,13 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                        blk_raw, blk_pos, scal, e->part.as<u32>(), nb, e->ncell);
     KSP_HIP(hipGetLastError());
     return KSP_OK;
+}
+
+// tag type of a build: 64-bit (weighted), compact 16-bit (unweighted, <= 65536 sources) or canonical 32-bit
+static int build_dispatch(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStream_t st, const int phase) {
+    if (e->weighted) return build_impl<u64>(e, d_keys, d_w, st, phase);
+    if (e->n_sources <= 65536u && !std::getenv("KSP_TAG32")) return build_impl<u16>(e, d_keys, d_w, st, phase);
+    return build_impl<u32>(e, d_keys, d_w, st, phase);
 }
 
 // Last step of stage 1 (single build and assemble alike): the bitmap of block pairs that share a
@@ -655,7 +662,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     if (const char* ro = std::getenv("KSP_REORDER")) e->reorder = std::atoi(ro) != 0;   // diagnostic / tests
     for (int attempt = 0; attempt < 2; ++attempt) {
         const int phase = slice ? 1 : 0;   // a slice stops at the source labels (ksp_engine_slice_finish does the rest)
-        rc = e->weighted ? build_impl<true>(e, d_keys, d_weights, st, phase) : build_impl<false>(e, d_keys, d_weights, st, phase);
+        rc = build_dispatch(e, d_keys, d_weights, st, phase);
         if (rc) return rc;
         KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 64, hipMemcpyDeviceToHost, st));
         KSP_HIP(hipStreamSynchronize(st));
@@ -745,7 +752,7 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
     e->post_src = d_sources;
     e->post_w = d_key_weights;
     e->post_nkeys = n_keys;
-    rc = e->weighted ? build_impl<true>(e, nullptr, nullptr, st, 3) : build_impl<false>(e, nullptr, nullptr, st, 3);
+    rc = build_dispatch(e, nullptr, nullptr, st, 3);
     e->post_off = e->post_src = e->post_w = nullptr;
     if (rc) return rc;
     KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 64, hipMemcpyDeviceToHost, st));
@@ -811,7 +818,7 @@ int ksp_engine_slice_finish(ksp_engine* e, const uint32_t* d_labels, void* strea
     int rc;
     KSP_HIP(hipEventRecord(e->ev[0], st));
     if (d_labels) KSP_HIP(hipMemcpyAsync(label_array(e), d_labels, (size_t)e->n_sources * 4, hipMemcpyDeviceToDevice, st));
-    rc = e->weighted ? build_impl<true>(e, nullptr, nullptr, st, 2) : build_impl<false>(e, nullptr, nullptr, st, 2);
+    rc = build_dispatch(e, nullptr, nullptr, st, 2);
     if (rc) return rc;
     KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 64, hipMemcpyDeviceToHost, st));
     if (e->n_kept == 0) {

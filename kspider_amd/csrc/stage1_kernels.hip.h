@@ -3,6 +3,19 @@
 // Included by engine.hip inside namespace ksp (one translation unit: the kernels are templates over the
 // tag type and share the constants defined there).  Host orchestration: build_impl in engine.hip.
 #pragma once
+
+// Entry tags.  Canonical form: (block << 8) | local id in 32 bits; weighted input carries the key's weight in
+// the high half of a 64-bit tag.  Unweighted sets of up to 65 536 sources use the compact form — the source
+// index itself in 16 bits — which takes 2 bytes per entry out of every pass of the two radix sorts.
+typedef unsigned short u16;
+template <class V> __host__ __device__ inline u32 tag_of(V v) { return (u32)v; }
+template <> __host__ __device__ inline u32 tag_of<u16>(u16 v) { return (((u32)v >> 7) << 8) | ((u32)v & 127u); }
+template <class V> __host__ __device__ inline V make_tag(u32 canon, u32 w) { (void)w; return (V)canon; }
+template <> __host__ __device__ inline u64 make_tag<u64>(u32 canon, u32 w) { return ((u64)w << 32) | canon; }
+template <> __host__ __device__ inline u16 make_tag<u16>(u32 canon, u32 w) { (void)w; return (u16)(((canon >> 8) << 7) | (canon & 127u)); }
+template <class V> __host__ __device__ inline u32 weight_of(V v) { (void)v; return 0u; }
+template <> __host__ __device__ inline u32 weight_of<u64>(u64 v) { return (u32)(v >> 32); }
+static_assert(TB == 128, "compact tags: 7-bit local ids");
 // ------------------------------------------------------------------------------------
 // stage 1 kernels
 // ------------------------------------------------------------------------------------
@@ -10,9 +23,9 @@
 // One workgroup per source: tag each entry with (block << 8 | local id) [and weight].
 // Weighted mode also records the source's weight sum (the bound of any pair counter that source
 // takes part in; unweighted: k_src_size).
-template <bool W>
-__global__ void k_tag(const u64* __restrict__ off, const u32* __restrict__ wts, u32* __restrict__ val32,
-                      u64* __restrict__ val64, u32* __restrict__ src_bound) {
+template <class V, bool W>
+__global__ void k_tag(const u64* __restrict__ off, const u32* __restrict__ wts, V* __restrict__ vals,
+                      u32* __restrict__ src_bound) {
     __shared__ unsigned long long acc;
     const u32 s = blockIdx.x;
     const u64 b = off[s], e = off[s + 1];
@@ -20,8 +33,8 @@ __global__ void k_tag(const u64* __restrict__ off, const u32* __restrict__ wts, 
     if (W) { if (threadIdx.x == 0) acc = 0; __syncthreads(); }
     unsigned long long part = 0;
     for (u64 i = b + threadIdx.x; i < e; i += blockDim.x) {
-        if (W) { const u32 w = wts[i]; part += w; val64[i] = ((u64)w << 32) | tag; }
-        else val32[i] = tag;
+        if (W) { const u32 w = wts[i]; part += w; vals[i] = make_tag<V>(tag, w); }
+        else vals[i] = make_tag<V>(tag, 0u);
     }
     if (W) {
         if (part) atomicAdd(&acc, part);
@@ -55,8 +68,8 @@ __global__ void k_label(const u32* __restrict__ rk, const V* __restrict__ vals, 
     // a key held by very many sources says nothing about who is related to whom — it would only pull
     // unrelated clusters under one label (first[] has a sentinel: first[U] = number of entries)
     if (first[r + 1] - f0 > max_holders) return;
-    const u32 s = src_of_tag((u32)vals[e]);
-    const u32 f = src_of_tag((u32)vals[f0]);   // entries of a key are in ascending source order
+    const u32 s = src_of_tag(tag_of(vals[e]));
+    const u32 f = src_of_tag(tag_of(vals[f0]));   // entries of a key are in ascending source order
     if (f < label[s]) atomicMin(&label[s], f);
 }
 // Postings input (an inverted index: per key its holders, e.g. the reference's colour -> sources map):
@@ -73,7 +86,7 @@ __global__ void k_post_expand(const u32* __restrict__ koff, const u32* __restric
         u32 s = src[e];
         if (s >= n_sources) { *bad = 1; s = 0; }   // reported as KSP_E_ARG by the caller; keep the stores in bounds
         const u32 tag = ((s / TB) << 8) | (s % TB);
-        vals[e] = W ? (V)(((u64)w << 32) | tag) : (V)tag;
+        vals[e] = make_tag<V>(tag, W ? w : 0u);
         rk[e] = r;
         if (w) atomicAdd(&src_bound[s], w);   // (the caller guarantees sums below 2^32)
     }
@@ -88,8 +101,8 @@ __global__ void k_retag(V* __restrict__ vals, const u32* __restrict__ newidx, u6
     u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const V v = vals[e];
-    const u32 ni = newidx[src_of_tag((u32)v)];
-    vals[e] = (V)((v & ~(V)0xFFFFFFFFu) | (V)(((ni / TB) << 8) | (ni % TB)));
+    const u32 ni = newidx[src_of_tag(tag_of(v))];
+    vals[e] = make_tag<V>(((ni / TB) << 8) | (ni % TB), weight_of(v));
 }
 // per block (of the new order): the largest per-source bound
 __global__ void k_blk_bound(const u32* __restrict__ src_bound, const u32* __restrict__ newidx, u32* __restrict__ blk_max,
@@ -98,7 +111,6 @@ __global__ void k_blk_bound(const u32* __restrict__ src_bound, const u32* __rest
     if (s < n_sources) atomicMax(&blk_max[newidx[s] / TB], src_bound[s]);
 }
 
-template <class V> __device__ inline u32 tag_of(V v) { return (u32)v; }
 
 // The global sort only looks at the top 32 significant bits of the keys (4 radix passes
 // instead of up to 8).  Entries whose keys agree in those bits are adjacent afterwards;
@@ -396,7 +408,7 @@ __global__ void k_emit_info(const u32* __restrict__ estart, const u32* __restric
     V v0 = vals[b];
     u32 blk = tag_of(v0) >> 8;
     u32 dst = blk_pos[blk] + ((u32)d - blk_raw[blk]);
-    if (W) bw[dst] = (u32)((u64)v0 >> 32);
+    if (W) bw[dst] = weight_of(v0);
     if (c <= INLINE_MAX) {
         u32 inf = (c - 1) << 29;
         for (u32 i = 0; i < c; ++i) inf |= (tag_of(vals[b + i]) & 0x7F) << (7 * i);
@@ -510,8 +522,7 @@ __global__ void k_range_copy(const u64* __restrict__ keys, const u32* __restrict
     const u32 tag = ((s / TB) << 8) | (s % TB);
     for (u32 i = threadIdx.x; i < c; i += blockDim.x) {
         fkeys[dst + i] = keys[src + i];
-        if (W) ftags[dst + i] = (V)(((u64)wts[src + i] << 32) | tag);
-        else ftags[dst + i] = (V)tag;
+        ftags[dst + i] = make_tag<V>(tag, W ? wts[src + i] : 0u);
     }
 }
 __global__ void k_range_total(const u32* __restrict__ fpos, const u32* __restrict__ cnt, u64* __restrict__ scal, u32 n_sources) {
