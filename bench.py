@@ -252,13 +252,13 @@ def main():
                          "note": "algorithmic bytes = SURVEY 8(d): sum over the launch's source pairs of "
                                  "8(n_a+n_b)+4; the kernel streams block-merged rank lists instead, "
                                  "see stream_model"},
-            "stage1_sort": (lambda ms, n_e, bits: {
+            "stage1_sort": (lambda ms, n_e, bits, tb=(2 if n <= 65536 and not os.environ.get("KSP_TAG32") else 4): {
                 "kernel": "rocprim radix_sort_onesweep (global sort of stage 1: the largest kernel group of the step)",
                 "entries": n_e, "key_bits": bits, "passes": (bits + 7) // 8, "ms": ms,
-                "bytes": n_e * 12 * 2 * ((bits + 7) // 8),
-                "GBps": (n_e * 12 * 2 * ((bits + 7) // 8)) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
-                "frac_of_hbm_peak": (n_e * 12 * 2 * ((bits + 7) // 8)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
-                "note": "8-byte key + 4-byte tag read and written once per 8-bit pass (histogram pass not counted)"})(
+                "bytes": n_e * (8 + tb) * 2 * ((bits + 7) // 8),
+                "GBps": (n_e * (8 + tb) * 2 * ((bits + 7) // 8)) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                "frac_of_hbm_peak": (n_e * (8 + tb) * 2 * ((bits + 7) // 8)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
+                "note": f"8-byte key + {tb}-byte tag read and written once per 8-bit pass (histogram pass not counted)"})(
                     stats.get("ms_sort", 0.0) / max(1, args.steps), int(stats.get("sort_entries", 0)), int(stats.get("sort_bits", 0))),
             "stream_model": {"bytes_per_launch": stats["stream_bytes"], "GBps": stream_gbs,
                              "frac_of_peak": stream_gbs / HBM_PEAK_GBS,
