@@ -95,7 +95,7 @@ def test_work_list_and_balanced_cuts(c2):
 
 
 @pytest.mark.parametrize("cfg,n,env", [("C4", 6000, {}), ("C4", 6000, {"KSP_NO_SCHED": "1"}),
-                                       ("C5", 60000, {}), ("C3", 5000, {"KSP_REORDER": "0"})])
+                                       ("C5", 70000, {}), ("C3", 5000, {"KSP_REORDER": "0"})])
 def test_other_shapes_checksum_and_samples(cfg, n, env, monkeypatch):
     """Shapes the small oracle cases do not reach (lognormal sizes with 32-bit-counter tiles, many tiny
     sketches, tiles whose search rounds find nothing): sum of all counts == sum_k C(holders_k, 2) from an
