@@ -107,6 +107,7 @@ struct ksp_engine {
     u32 ncell = ksp::NP;          // fine rank cells per block (power of two)
     bool use_cells = true;        // rank-aligned cell join (KSP_JOIN=window selects the sliding-window merge)
     bool full_sort = false;       // keys defeat the 32-bit prefix sort: use all bits
+    bool hash_off = false;        // keys defeat the bucket grouping (a bucket overflowed): use the sort path
     bool reorder = true;          // order the sources by shared-key label before cutting blocks (KSP_REORDER=0: off)
     bool need32 = false;          // some tile pairs two blocks that both hold a source with >= 2^16 k-mers
     int key_bits = 64;
@@ -208,8 +209,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         }
         if (reorder) {
             const u32 skip = m / std::max<u32>(1, N) >= 512 ? 7u : 0u;
-            hipLaunchKernelGGL((k_label<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, VA, e->post_off, label, skip,
-                               label_max, m);
+            hipLaunchKernelGGL((k_label<V>), dim3(grid_for(nk, bs)), dim3(bs), 0, st, VA, e->post_off, label, skip,
+                               label_max, nk);
         } else {
             hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
         }
@@ -283,6 +284,51 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     u32* d_ovf = (u32*)(scal + 4);   // set by k_fix_runs when a run is too long; checked at the end of the build
     KSP_HIP(hipMemsetAsync(d_ovf, 0, 8, st));
     tb = 0;
+    // grouping by hash bucket (see k_bucket_group): partition on the top pb key bits only — buckets of
+    // ~500-2000 entries for uniform hashes, whatever fraction of [0, 2^kbits) the keys really span
+    int pb = 0;
+    if (phase == 0 && !e->hash_off && !e->full_sort && kbits < 64 && nw >= 4096) {
+        pb = 1;
+        while ((nw >> pb) > 1024) ++pb;
+        if (pb > kbits) pb = 0;   // (few distinct keys, many holders each: the sort path)
+    }
+    if ((rc = e->FK.ensure((nw / 2 + 16) * 4))) return rc;
+    u32* first = (u32*)e->FK.p;            // first kept entry of every rank (FK: the slice's input keys are dead after sort 1)
+    if (pb) {
+        const int shiftb = kbits - pb;
+        const u32 nbuckets = 1u << pb;
+        KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, KA, tags_in, VB, nw, shiftb, kbits, st));
+        if ((rc = e->tmp.ensure(tb))) return rc;
+        KSP_HIP(hipEventRecord(e->ev[4], st));
+        KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, keys_in, KA, tags_in, VB, nw, shiftb, kbits, st));
+        KSP_HIP(hipEventRecord(e->ev[5], st));
+        e->sort_entries = nw;
+        e->sort_bits = pb;
+        // KB is free until the grouping scans: per-entry records, then the bucket tables
+        u32* rec = (u32*)e->KB.p;
+        u64* bsum = (u64*)e->KB.p + (nw / 2 + 1);
+        u64* bbase = bsum + nbuckets;
+        u32* bstart = (u32*)(bbase + nbuckets);   // nbuckets + 1
+        u32* d_hovf = (u32*)(scal + 9);
+        KSP_HIP(hipMemsetAsync(d_hovf, 0, 8, st));
+        hipLaunchKernelGGL(k_bucket_bounds, dim3(grid_for((u64)nbuckets + 1, bs)), dim3(bs), 0, st, KA, nw, shiftb, nbuckets,
+                           bstart);
+        hipLaunchKernelGGL(k_bucket_group, dim3(nbuckets), dim3(256), 0, st, KA, bstart, rec, bsum, d_hovf);
+        size_t tb2 = 0;
+        KSP_HIP(rocprim::exclusive_scan(nullptr, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
+        if ((rc = e->tmp.ensure(tb2))) return rc;
+        KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
+        hipLaunchKernelGGL((k_bucket_emit<V>), dim3(nbuckets), dim3(256), 0, st, rec, VB, bstart, bbase, bsum, nbuckets, VA,
+                           rank1, first, scal);
+        KSP_HIP(hipMemcpyAsync(e->h_scal + 2, scal + 2, 8, hipMemcpyDeviceToHost, st));
+        KSP_HIP(hipMemcpyAsync(e->h_scal + 6, scal + 6, 8, hipMemcpyDeviceToHost, st));
+        KSP_HIP(hipMemcpyAsync(e->h_scal + 9, scal + 9, 8, hipMemcpyDeviceToHost, st));
+        KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
+        if ((u32)e->h_scal[9]) {   // a bucket did not fit (skewed keys): this engine sorts from now on
+            e->hash_off = true;
+            return build_impl<V>(e, d_keys, d_w, st, phase);
+        }
+    } else {
     KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, KA, tags_in, VB, nw, shift, kbits, st));
     if ((rc = e->tmp.ensure(tb))) return rc;
     KSP_HIP(hipEventRecord(e->ev[4], st));
@@ -304,8 +350,6 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     }
     // singleton pruning + dense ranks of the kept keys (packed counters, one scan):  KA,VB -> R1 (ranks), VA (tags)
     // (the scan's output iterator scatters entry e as soon as its prefix sums are known: no second pass)
-    if ((rc = e->FK.ensure((nw / 2 + 16) * 4))) return rc;
-    u32* first = (u32*)e->FK.p;            // first kept entry of every rank (FK: the slice's input keys are dead after sort 1)
     {
         auto pf = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u64>(0), PruneFn{KA, nw});
         PruneScatterIt<V> out{{KA, VB, VA, rank1, first, scal, nw}, 0};
@@ -314,8 +358,10 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         if ((rc = e->tmp.ensure(tb))) return rc;
         KSP_HIP(rocprim::inclusive_scan(e->tmp.p, tb, pf, out, nw, rocprim::plus<u64>(), st));
     }
+    KSP_HIP(hipMemcpyAsync(e->h_scal + 2, scal + 2, 8, hipMemcpyDeviceToHost, st));
     KSP_HIP(hipMemcpyAsync(e->h_scal + 6, scal + 6, 8, hipMemcpyDeviceToHost, st));
     KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
+    }
     m = e->h_scal[6];
     e->n_kept = m;
     if (m == 0 && phase == 0) return KSP_OK;   // no key is shared by two sources: no pair at all
@@ -323,8 +369,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         // label = smallest source id among the holders of a source's shared keys
         // (sources with hundreds of shared keys: every 8th key says as much about a source's relatives as all)
         const u32 skip = m / std::max<u32>(1, N) >= 512 ? 7u : 0u;
-        hipLaunchKernelGGL((k_label<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rank1, VA, first, label, skip,
-                           label_max, m);
+        const u32 U = (u32)e->h_scal[2];
+        hipLaunchKernelGGL((k_label<V>), dim3(grid_for(U, bs)), dim3(bs), 0, st, VA, first, label, skip, label_max, U);
     }
     if (phase == 1) return KSP_OK;
     }   // phase != 2
@@ -629,6 +675,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     e->part_id = part;
     e->h_off.assign(h_offsets, h_offsets + n_sources + 1);
     if (std::getenv("KSP_FULL_SORT")) e->full_sort = true;   // diagnostic: sort on all key bits
+    if (const char* hg = std::getenv("KSP_HASH_GROUP")) e->hash_off = std::atoi(hg) == 0;   // diagnostic / tests
     e->st = ksp_stats{};
     e->st.n_sources = n_sources;
     e->st.n_entries = n;

@@ -60,17 +60,20 @@ __global__ void k_iota(u32* __restrict__ p, u32 n) {
 }
 __device__ inline u32 src_of_tag(u32 t) { return (t >> 8) * TB + (t & 0xFFu); }
 template <class V>
-__global__ void k_label(const u32* __restrict__ rk, const V* __restrict__ vals, const u32* __restrict__ first,
-                        u32* __restrict__ label, const u32 skip, const u32 max_holders, u64 n) {
-    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n || (rk[e] & skip)) return;
-    const u32 r = rk[e], f0 = first[r];
+__global__ void k_label(const V* __restrict__ vals, const u32* __restrict__ first, u32* __restrict__ label,
+                        const u32 skip, const u32 max_holders, u32 n_keys) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per kept key
+    if (r >= n_keys || (r & skip)) return;
+    const u32 f0 = first[r], f1 = first[r + 1];   // (first[] has a sentinel: first[U] = number of entries)
     // a key held by very many sources says nothing about who is related to whom — it would only pull
-    // unrelated clusters under one label (first[] has a sentinel: first[U] = number of entries)
-    if (first[r + 1] - f0 > max_holders) return;
-    const u32 s = src_of_tag(tag_of(vals[e]));
-    const u32 f = src_of_tag(tag_of(vals[f0]));   // entries of a key are in ascending source order
-    if (f < label[s]) atomicMin(&label[s], f);
+    // unrelated clusters under one label
+    if (f1 - f0 > max_holders) return;
+    u32 mn = ~0u;   // (the entries of a key are in no particular order after the bucket grouping)
+    for (u32 e = f0; e < f1; ++e) mn = min(mn, src_of_tag(tag_of(vals[e])));
+    for (u32 e = f0; e < f1; ++e) {
+        const u32 s = src_of_tag(tag_of(vals[e]));
+        if (mn < label[s]) atomicMin(&label[s], mn);
+    }
 }
 // Postings input (an inverted index: per key its holders, e.g. the reference's colour -> sources map):
 // the state stage 1 reaches after sorting and pruning, written directly — entry tags, the key index as
@@ -239,6 +242,138 @@ __global__ __launch_bounds__(256) void k_fix_runs(u64* __restrict__ keys, V* __r
             keys[j] = k;
             vals[j] = v;
         }
+    }
+}
+
+// ---- grouping by hash bucket: two partition passes instead of a full sort ------------------------
+// The engine does not need the keys in order — only equal keys together, a consistent dense rank per
+// key, and the keys held by one source dropped.  So the entries are only *partitioned* by their top
+// `pb` key bits (two 8-bit radix passes for ~30 000 buckets of ~1500 entries; sketch hashes are uniform),
+// and one workgroup per bucket groups its entries in an LDS hash table keyed by the full 64-bit key:
+// count per key, drop the singletons, number the kept keys, and give every kept entry its place —
+// the entries of a key contiguous, keys in slot order.  Bucket offsets come from one small scan, and a
+// second light kernel moves the tags.  This replaces the other two radix passes, the mixed-run fix-up
+// and the prune scan (2.4 -> 1.3 ms on C2).  A bucket that does not fit (skewed keys) sends the build
+// back to the sort path.
+constexpr u32 HB_CAP = 3072;     // entries per bucket (one 16-bit slot index each in LDS)
+constexpr u32 HB_SLOTS = 4096;   // hash slots per bucket (power of two; more than HB_CAP: never full)
+constexpr u32 HB_KEPT = 1u << 31, HB_FIRST = 1u << 30;   // per-entry record: kept | first of its key | rank << 12 | place
+
+__global__ void k_bucket_bounds(const u64* __restrict__ keys, u64 n, int shiftb, u32 nbuckets, u32* __restrict__ bstart) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nbuckets) return;
+    u64 lo = 0, hi = n;
+    if (b == nbuckets) lo = n;
+    while (lo < hi) {
+        const u64 mid = lo + ((hi - lo) >> 1);
+        if ((keys[mid] >> shiftb) < (u64)b) lo = mid + 1; else hi = mid;
+    }
+    bstart[b] = (u32)lo;
+}
+
+__global__ __launch_bounds__(256) void k_bucket_group(const u64* __restrict__ keys, const u32* __restrict__ bstart,
+                                                      u32* __restrict__ rec, u64* __restrict__ bsum,
+                                                      u32* __restrict__ overflow) {
+    __shared__ unsigned long long tkey[HB_SLOTS + 1];
+    __shared__ u32 tcnt[HB_SLOTS + 1];   // low 16 bits: entries of the key; high 16 bits: fill cursor
+    __shared__ u32 toff[HB_SLOTS + 1];   // first place of the key's entries | its rank << 16
+    __shared__ unsigned short eslot[HB_CAP];
+    __shared__ u64 wpart[4];
+    const u32 b = blockIdx.x, tid = threadIdx.x;
+    const u32 b0 = bstart[b], size = bstart[b + 1] - b0;
+    if (size > HB_CAP) {   // does not fit: the host falls back to the sort path
+        if (tid == 0) { *overflow = 1; bsum[b] = 0; }
+        return;
+    }
+    constexpr unsigned long long EMPTY = ~0ull;
+    // every thread's keys are fetched before the table work starts (one memory round trip per bucket)
+    constexpr u32 EPT = HB_CAP / 256;
+    unsigned long long mykey[EPT];
+#pragma unroll
+    for (u32 j = 0; j < EPT; ++j) mykey[j] = tid + j * 256 < size ? keys[b0 + tid + j * 256] : 0;
+    for (u32 i = tid; i <= HB_SLOTS; i += 256) { tkey[i] = EMPTY; tcnt[i] = 0; }
+    __syncthreads();
+#pragma unroll
+    for (u32 j = 0; j < EPT; ++j) {
+        const u32 i = tid + j * 256;
+        if (i >= size) break;
+        const unsigned long long key = mykey[j];
+        u32 h;
+        if (key == EMPTY) {
+            h = HB_SLOTS;   // the one key that looks like an empty slot has a slot of its own
+        } else {
+            h = (u32)((key * 0x9E3779B97F4A7C15ull) >> 52) & (HB_SLOTS - 1);
+            while (true) {
+                const unsigned long long prev = atomicCAS(&tkey[h], EMPTY, key);
+                if (prev == EMPTY || prev == key) break;
+                h = (h + 1) & (HB_SLOTS - 1);
+            }
+        }
+        eslot[i] = (unsigned short)h;
+        atomicAdd(&tcnt[h], 1u);
+    }
+    __syncthreads();
+    // exclusive scan over the slots of (kept entries | kept keys << 32): 17 slots per thread
+    constexpr u32 PER = (HB_SLOTS + 1 + 255) / 256;
+    u64 mine = 0;
+    for (u32 j = 0; j < PER; ++j) {
+        const u32 sl = tid * PER + j;
+        if (sl <= HB_SLOTS) { const u32 c = tcnt[sl]; if (c >= 2) mine += (u64)c | (1ull << 32); }
+    }
+    const int lane = tid & 63, wv = tid >> 6;
+    u64 inc = mine;
+    for (int o = 1; o < 64; o <<= 1) { const u64 up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+    if (lane == 63) wpart[wv] = inc;
+    __syncthreads();
+    u64 run = inc - mine;
+    for (int w = 0; w < wv; ++w) run += wpart[w];
+    for (u32 j = 0; j < PER; ++j) {
+        const u32 sl = tid * PER + j;
+        if (sl <= HB_SLOTS) {
+            const u32 c = tcnt[sl];
+            toff[sl] = (u32)run | ((u32)(run >> 32) << 16);
+            if (c >= 2) run += (u64)c | (1ull << 32);
+        }
+    }
+    if (tid == 255) bsum[b] = run;   // (the last thread's running total is the bucket's total)
+    __syncthreads();
+    for (u32 i = tid; i < size; i += 256) {
+        const u32 sl = eslot[i];
+        u32 r = 0;
+        if ((tcnt[sl] & 0xFFFFu) >= 2) {
+            const u32 fill = atomicAdd(&tcnt[sl], 1u << 16) >> 16;
+            const u32 t = toff[sl];
+            r = HB_KEPT | (fill == 0 ? HB_FIRST : 0u) | ((t >> 16) << 12) | ((t & 0xFFFFu) + fill);
+        }
+        rec[b0 + i] = r;
+    }
+}
+
+// kept entries to their final places: bucket base (from the scan over the buckets) + place inside the bucket
+template <class V>
+__global__ __launch_bounds__(256) void k_bucket_emit(const u32* __restrict__ rec, const V* __restrict__ vals,
+                                                     const u32* __restrict__ bstart, const u64* __restrict__ bbase,
+                                                     const u64* __restrict__ bsum, u32 nbuckets, V* __restrict__ vals2,
+                                                     u32* __restrict__ rank2, u32* __restrict__ first,
+                                                     u64* __restrict__ scal) {
+    const u32 b = blockIdx.x;
+    const u32 b0 = bstart[b], size = bstart[b + 1] - b0;
+    const u64 base = bbase[b];
+    const u32 ebase = (u32)base, kbase = (u32)(base >> 32);
+    for (u32 i = threadIdx.x; i < size; i += 256) {
+        const u32 r = rec[b0 + i];
+        if (r & HB_KEPT) {
+            const u32 p = ebase + (r & 0xFFFu), rk = kbase + ((r >> 12) & 0xFFFu);
+            vals2[p] = vals[b0 + i];
+            rank2[p] = rk;
+            if (r & HB_FIRST) first[rk] = p;
+        }
+    }
+    if (b == nbuckets - 1 && threadIdx.x == 0) {
+        const u64 tot = base + bsum[b];
+        scal[6] = (u32)tot;           // kept entries
+        scal[2] = (u32)(tot >> 32);   // kept distinct keys (U)
+        first[(u32)(tot >> 32)] = (u32)tot;   // sentinel
     }
 }
 

@@ -10,14 +10,17 @@ from kspider_amd import engine, synth
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default", "no_reorder", "dense_walk", "collect", "lds_counters"])
+@pytest.fixture(autouse=True, params=["default", "no_reorder", "dense_walk", "collect", "lds_counters", "sort_grouping"])
 def mode(request, monkeypatch):
-    """Every case runs five ways: as shipped (sources reordered by shared-key label, join over the
+    """Every case runs six ways (the last: keys grouped by the full sort instead of the hash buckets,
+    KSP_HASH_GROUP=0): as shipped (sources reordered by shared-key label, join over the
     work list of active tiles, accumulation chosen by the postings' sizes), with the caller's source
     order (KSP_REORDER=0), with the reordering but a plain walk over all tiles (KSP_NO_SCHED=1), and with
     the off-diagonal accumulation forced to the bit-sliced collect path / to the LDS counters."""
-    for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT"):
+    for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_HASH_GROUP"):
         monkeypatch.delenv(k, raising=False)
+    if request.param == "sort_grouping":
+        monkeypatch.setenv("KSP_HASH_GROUP", "0")
     if request.param == "no_reorder":
         monkeypatch.setenv("KSP_REORDER", "0")
     elif request.param == "dense_walk":
@@ -132,6 +135,32 @@ def test_keys_sharing_their_top_bits(oracle_lib):
     giant = base | rng.integers(0, 1 << 31, size=5000, dtype=np.uint64)
     runs = [np.unique(giant[rng.integers(0, giant.size, size=300)]) for _ in range(150)]
     _check(synth.from_runs(runs), oracle_lib)
+
+
+def test_bucket_grouping_and_its_fallback(oracle_lib, mode):
+    """Uniform hashes below 2^64 are grouped in LDS hash buckets (two partition passes); a bucket that
+    does not fit — thousands of distinct keys under one prefix, or one key held by thousands of
+    sources — sends the build back to the sort path.  Same edges either way."""
+    rng = np.random.default_rng(31)
+    sk = synth.generate("C2", n_sources=400, mean_size=600, cluster_cap=20, seed=77)
+    _, st = _check(sk, oracle_lib)
+    if mode != "sort_grouping":
+        assert 0 < st["sort_bits"] <= 16, st["sort_bits"]        # partitioned, not sorted
+    else:
+        assert st["sort_bits"] >= 32
+    # 6000 distinct keys under one 30-bit prefix, among uniform ones
+    crowd = (np.uint64(0x2345678) << np.uint64(30)) | rng.integers(0, 1 << 30, size=6000, dtype=np.uint64)
+    runs = []
+    for s in range(300):
+        wide = rng.integers(0, 1 << 58, size=200, dtype=np.uint64)
+        runs.append(np.unique(np.concatenate([wide, crowd[rng.integers(0, crowd.size, size=120)]])))
+    _, st = _check(synth.from_runs(runs), oracle_lib)
+    assert st["sort_bits"] >= 32
+    # one key held by every one of 3500 sources
+    runs = [np.unique(np.concatenate([[np.uint64(123456789)], rng.integers(0, 1 << 50, size=3, dtype=np.uint64)]))
+            for _ in range(3500)]
+    _, st = _check(synth.from_runs(runs), oracle_lib)
+    assert st["sort_bits"] >= 32
 
 
 def test_rank_skew_takes_the_oversized_cell_path(oracle_lib):

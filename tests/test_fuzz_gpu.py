@@ -9,7 +9,7 @@ from kspider_amd import engine, synth
 pytestmark = pytest.mark.gpu
 
 MODES = [{}, {"KSP_REORDER": "0"}, {"KSP_NO_SCHED": "1"}, {"KSP_COLLECT": "1"}, {"KSP_COLLECT": "0"},
-         {"KSP_JOIN": "window"}, {"KSP_TAG32": "1"}]
+         {"KSP_JOIN": "window"}, {"KSP_TAG32": "1"}, {"KSP_HASH_GROUP": "0"}]
 
 
 def _random_sketches(rng):
@@ -36,7 +36,7 @@ def test_random_sketches_all_modes(oracle_lib, seed, monkeypatch):
         sk = _random_sketches(rng)
         ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
         for env in MODES:
-            for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_JOIN", "KSP_TAG32"):
+            for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_JOIN", "KSP_TAG32", "KSP_HASH_GROUP"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
