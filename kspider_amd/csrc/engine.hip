@@ -108,6 +108,7 @@ struct ksp_engine {
     bool use_cells = true;        // rank-aligned cell join (KSP_JOIN=window selects the sliding-window merge)
     bool full_sort = false;       // keys defeat the 32-bit prefix sort: use all bits
     bool hash_off = false;        // keys defeat the bucket grouping (a bucket overflowed): use the sort path
+    u32 hb_slots = 0;             // workgroups of k_bucket_group the device holds at once
     bool reorder = true;          // order the sources by shared-key label before cutting blocks (KSP_REORDER=0: off)
     bool need32 = false;          // some tile pairs two blocks that both hold a source with >= 2^16 k-mers
     int key_bits = 64;
@@ -285,11 +286,11 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     KSP_HIP(hipMemsetAsync(d_ovf, 0, 8, st));
     tb = 0;
     // grouping by hash bucket (see k_bucket_group): partition on the top pb key bits only — buckets of
-    // ~500-2000 entries for uniform hashes, whatever fraction of [0, 2^kbits) the keys really span
+    // 400-800 entries for uniform hashes (up to twice that when the keys span just over half of [0, 2^kbits))
     int pb = 0;
     if (phase == 0 && !e->hash_off && !e->full_sort && kbits < 64 && nw >= 4096) {
         pb = 1;
-        while ((nw >> pb) > 1024) ++pb;
+        while ((nw >> pb) > HB_MEAN) ++pb;
         if (pb > kbits) pb = 0;   // (few distinct keys, many holders each: the sort path)
     }
     if ((rc = e->FK.ensure((nw / 2 + 16) * 4))) return rc;
@@ -311,15 +312,23 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         u32* bstart = (u32*)(bbase + nbuckets);   // nbuckets + 1
         u32* d_hovf = (u32*)(scal + 9);
         KSP_HIP(hipMemsetAsync(d_hovf, 0, 8, st));
+        KSP_HIP(hipMemsetAsync(bsum, 0, (size_t)nbuckets * 8, st));
         hipLaunchKernelGGL(k_bucket_bounds, dim3(grid_for((u64)nbuckets + 1, bs)), dim3(bs), 0, st, KA, nw, shiftb, nbuckets,
                            bstart);
-        hipLaunchKernelGGL(k_bucket_group, dim3(nbuckets), dim3(256), 0, st, KA, bstart, rec, bsum, d_hovf);
+        if (!e->hb_slots) {   // persistent workgroups: as many as fit on the device at once
+            int per_cu = 0, cus = 0;
+            KSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bucket_group, HB_THREADS, 0));
+            KSP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+            e->hb_slots = (u32)std::max(1, per_cu * cus);
+        }
+        hipLaunchKernelGGL(k_bucket_group, dim3(std::min(nbuckets, e->hb_slots)), dim3(HB_THREADS), 0, st, KA, bstart,
+                           nbuckets, (u32)nw, rec, bsum, d_hovf);
         size_t tb2 = 0;
         KSP_HIP(rocprim::exclusive_scan(nullptr, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
         if ((rc = e->tmp.ensure(tb2))) return rc;
         KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
-        hipLaunchKernelGGL((k_bucket_emit<V>), dim3(nbuckets), dim3(256), 0, st, rec, VB, bstart, bbase, bsum, nbuckets, VA,
-                           rank1, first, scal);
+        hipLaunchKernelGGL((k_bucket_emit<V>), dim3((nbuckets + HB_EMIT - 1) / HB_EMIT), dim3(HB_THREADS), 0, st, rec, VB, bstart,
+                           bbase, bsum, nbuckets, VA, rank1, first, scal);
         KSP_HIP(hipMemcpyAsync(e->h_scal + 2, scal + 2, 8, hipMemcpyDeviceToHost, st));
         KSP_HIP(hipMemcpyAsync(e->h_scal + 6, scal + 6, 8, hipMemcpyDeviceToHost, st));
         KSP_HIP(hipMemcpyAsync(e->h_scal + 9, scal + 9, 8, hipMemcpyDeviceToHost, st));

@@ -248,16 +248,24 @@ __global__ __launch_bounds__(256) void k_fix_runs(u64* __restrict__ keys, V* __r
 // ---- grouping by hash bucket: two partition passes instead of a full sort ------------------------
 // The engine does not need the keys in order — only equal keys together, a consistent dense rank per
 // key, and the keys held by one source dropped.  So the entries are only *partitioned* by their top
-// `pb` key bits (two 8-bit radix passes for ~30 000 buckets of ~1500 entries; sketch hashes are uniform),
-// and one workgroup per bucket groups its entries in an LDS hash table keyed by the full 64-bit key:
-// count per key, drop the singletons, number the kept keys, and give every kept entry its place —
-// the entries of a key contiguous, keys in slot order.  Bucket offsets come from one small scan, and a
-// second light kernel moves the tags.  This replaces the other two radix passes, the mixed-run fix-up
-// and the prune scan (2.4 -> 1.3 ms on C2).  A bucket that does not fit (skewed keys) sends the build
+// `pb` key bits (two 8-bit radix passes; sketch hashes are uniform), and one workgroup at a time
+// groups a bucket's entries in an LDS hash table keyed by the full 64-bit key: count per key, drop the
+// singletons, number the kept keys (slot order), and give every kept entry its place inside the
+// bucket — the entries of a key contiguous.  One small scan over the bucket totals and a streaming
+// kernel then move tags and ranks to their final places.  This replaces the other two radix passes,
+// the mixed-run fix-up and the prune scan.  A bucket that does not fit (skewed keys) sends the build
 // back to the sort path.
+// (A single-kernel variant — bucket offsets by decoupled look-back, tickets for the order — was
+//  measured at 1.1 ms against 0.41 ms for the same kernel without the look-back: the persistent
+//  workgroups move in step, so every look-back walks hundreds of predecessors.  Two kernels it is.)
 constexpr u32 HB_CAP = 3072;     // entries per bucket (one 16-bit slot index each in LDS)
 constexpr u32 HB_SLOTS = 4096;   // hash slots per bucket (power of two; more than HB_CAP: never full)
+constexpr u32 HB_THREADS = 512;
+// The host picks the bucket count for at most this mean size over [0, 2^key_bits); real hash ranges are
+// not powers of two (2^64 / scaled is 0.51 x 2^55 for scaled = 1000), so the mean can be twice that.
+constexpr u32 HB_MEAN = 800;
 constexpr u32 HB_KEPT = 1u << 31, HB_FIRST = 1u << 30;   // per-entry record: kept | first of its key | rank << 12 | place
+constexpr u32 HB_EMIT = 8;       // buckets per workgroup of the emit kernel
 
 __global__ void k_bucket_bounds(const u64* __restrict__ keys, u64 n, int shiftb, u32 nbuckets, u32* __restrict__ bstart) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,106 +279,164 @@ __global__ void k_bucket_bounds(const u64* __restrict__ keys, u64 n, int shiftb,
     bstart[b] = (u32)lo;
 }
 
-__global__ __launch_bounds__(256) void k_bucket_group(const u64* __restrict__ keys, const u32* __restrict__ bstart,
-                                                      u32* __restrict__ rec, u64* __restrict__ bsum,
-                                                      u32* __restrict__ overflow) {
+// Persistent workgroups, buckets b = blockIdx.x, += gridDim.x: while a bucket is grouped, the bounds
+// and then the keys of the workgroup's next bucket are already on their way (the kernel is a chain
+// of memory round trips otherwise).  bsum[] is zero at launch (trailing empty buckets are not visited).
+__global__ __launch_bounds__(HB_THREADS) void k_bucket_group(const u64* __restrict__ keys, const u32* __restrict__ bstart,
+                                                             u32 nbuckets, u32 nw, u32* __restrict__ rec,
+                                                             u64* __restrict__ bsum, u32* __restrict__ overflow) {
+    constexpr u32 NT = HB_THREADS, NWV = NT / 64;
     __shared__ unsigned long long tkey[HB_SLOTS + 1];
-    __shared__ u32 tcnt[HB_SLOTS + 1];   // low 16 bits: entries of the key; high 16 bits: fill cursor
-    __shared__ u32 toff[HB_SLOTS + 1];   // first place of the key's entries | its rank << 16
+    __shared__ u32 tcnt2[HB_SLOTS / 2 + 1];   // entries per key, two 16-bit counters per word
     __shared__ unsigned short eslot[HB_CAP];
-    __shared__ u64 wpart[4];
-    const u32 b = blockIdx.x, tid = threadIdx.x;
-    const u32 b0 = bstart[b], size = bstart[b + 1] - b0;
-    if (size > HB_CAP) {   // does not fit: the host falls back to the sort path
-        if (tid == 0) { *overflow = 1; bsum[b] = 0; }
-        return;
-    }
+    __shared__ u64 wpart[NWV];
+    // after the inserts the keys are dead and their storage holds, per slot, the first place of the key's
+    // entries | its rank << 16, and the fill cursor
+    u32* toff = (u32*)tkey;
+    u32* tfill = toff + (HB_SLOTS + 1);
     constexpr unsigned long long EMPTY = ~0ull;
-    // every thread's keys are fetched before the table work starts (one memory round trip per bucket)
-    constexpr u32 EPT = HB_CAP / 256;
-    unsigned long long mykey[EPT];
-#pragma unroll
-    for (u32 j = 0; j < EPT; ++j) mykey[j] = tid + j * 256 < size ? keys[b0 + tid + j * 256] : 0;
-    for (u32 i = tid; i <= HB_SLOTS; i += 256) { tkey[i] = EMPTY; tcnt[i] = 0; }
-    __syncthreads();
-#pragma unroll
-    for (u32 j = 0; j < EPT; ++j) {
-        const u32 i = tid + j * 256;
-        if (i >= size) break;
-        const unsigned long long key = mykey[j];
-        u32 h;
-        if (key == EMPTY) {
-            h = HB_SLOTS;   // the one key that looks like an empty slot has a slot of its own
-        } else {
-            h = (u32)((key * 0x9E3779B97F4A7C15ull) >> 52) & (HB_SLOTS - 1);
-            while (true) {
-                const unsigned long long prev = atomicCAS(&tkey[h], EMPTY, key);
-                if (prev == EMPTY || prev == key) break;
-                h = (h + 1) & (HB_SLOTS - 1);
-            }
-        }
-        eslot[i] = (unsigned short)h;
-        atomicAdd(&tcnt[h], 1u);
-    }
-    __syncthreads();
-    // exclusive scan over the slots of (kept entries | kept keys << 32): 17 slots per thread
-    constexpr u32 PER = (HB_SLOTS + 1 + 255) / 256;
-    u64 mine = 0;
-    for (u32 j = 0; j < PER; ++j) {
-        const u32 sl = tid * PER + j;
-        if (sl <= HB_SLOTS) { const u32 c = tcnt[sl]; if (c >= 2) mine += (u64)c | (1ull << 32); }
-    }
+    constexpr u32 EPT = HB_CAP / NT;
+    constexpr u32 PER = (HB_SLOTS + 1 + NT - 1) / NT;
+    const u32 tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    u64 inc = mine;
-    for (int o = 1; o < 64; o <<= 1) { const u64 up = __shfl_up(inc, o); if (lane >= o) inc += up; }
-    if (lane == 63) wpart[wv] = inc;
-    __syncthreads();
-    u64 run = inc - mine;
-    for (int w = 0; w < wv; ++w) run += wpart[w];
-    for (u32 j = 0; j < PER; ++j) {
-        const u32 sl = tid * PER + j;
-        if (sl <= HB_SLOTS) {
-            const u32 c = tcnt[sl];
-            toff[sl] = (u32)run | ((u32)(run >> 32) << 16);
-            if (c >= 2) run += (u64)c | (1ull << 32);
+    u32 b = blockIdx.x;
+    u32 b0 = nw, raw = 0;
+    if (b < nbuckets) { b0 = bstart[b]; raw = bstart[b + 1] - b0; }
+    u32 size = raw > HB_CAP ? 0 : raw;   // a bucket that does not fit is skipped: the host falls back to the sort path
+    unsigned long long mykey[EPT], nkey[EPT];
+#pragma unroll
+    for (u32 j = 0; j < EPT; ++j) mykey[j] = tid + j * NT < size ? keys[b0 + tid + j * NT] : 0;
+    while (b < nbuckets && b0 < nw) {   // (b0 == nw: this bucket and every later one is empty)
+        if (raw > HB_CAP && tid == 0) *overflow = 1;
+        const u32 bn = b + gridDim.x;
+        u32 n0 = nw, nraw = 0;          // bounds of the next bucket
+        if (bn < nbuckets) { n0 = bstart[bn]; nraw = bstart[bn + 1] - n0; }
+        for (u32 i = tid; i <= HB_SLOTS; i += NT) tkey[i] = EMPTY;
+        for (u32 i = tid; i <= HB_SLOTS / 2; i += NT) tcnt2[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (u32 j = 0; j < EPT; ++j) {
+            const u32 i = tid + j * NT;
+            if (i >= size) break;
+            const unsigned long long key = mykey[j];
+            u32 h;
+            if (key == EMPTY) {
+                h = HB_SLOTS;   // the one key that looks like an empty slot has a slot of its own
+            } else {
+                h = (u32)((key * 0x9E3779B97F4A7C15ull) >> 52) & (HB_SLOTS - 1);
+                while (true) {
+                    const unsigned long long prev = atomicCAS(&tkey[h], EMPTY, key);
+                    if (prev == EMPTY || prev == key) break;
+                    h = (h + 1) & (HB_SLOTS - 1);
+                }
+            }
+            eslot[i] = (unsigned short)h;
+            atomicAdd(&tcnt2[h >> 1], 1u << (16 * (h & 1)));
         }
-    }
-    if (tid == 255) bsum[b] = run;   // (the last thread's running total is the bucket's total)
-    __syncthreads();
-    for (u32 i = tid; i < size; i += 256) {
-        const u32 sl = eslot[i];
-        u32 r = 0;
-        if ((tcnt[sl] & 0xFFFFu) >= 2) {
-            const u32 fill = atomicAdd(&tcnt[sl], 1u << 16) >> 16;
-            const u32 t = toff[sl];
-            r = HB_KEPT | (fill == 0 ? HB_FIRST : 0u) | ((t >> 16) << 12) | ((t & 0xFFFFu) + fill);
+        // the next bucket's keys: in flight during the scan and the placement
+        const u32 nsize = nraw > HB_CAP ? 0 : nraw;
+#pragma unroll
+        for (u32 j = 0; j < EPT; ++j) nkey[j] = tid + j * NT < nsize ? keys[n0 + tid + j * NT] : 0;
+        __syncthreads();
+        // exclusive scan over the slots of (kept entries | kept keys << 32): 9 slots per thread
+        u32 cnt[PER];
+        u64 mine = 0;
+#pragma unroll
+        for (u32 j = 0; j < PER; ++j) {
+            const u32 sl = tid * PER + j;
+            cnt[j] = sl <= HB_SLOTS ? (tcnt2[sl >> 1] >> (16 * (sl & 1))) & 0xFFFFu : 0;
+            if (cnt[j] >= 2) mine += (u64)cnt[j] | (1ull << 32);
         }
-        rec[b0 + i] = r;
+        u64 inc = mine;
+        for (int o = 1; o < 64; o <<= 1) { const u64 up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+        if (lane == 63) wpart[wv] = inc;
+        __syncthreads();
+        u64 run = inc - mine;
+        for (int w = 0; w < wv; ++w) run += wpart[w];
+        if (tid == NT - 1) bsum[b] = run + mine;   // the last thread's inclusive sum: the bucket's total
+#pragma unroll
+        for (u32 j = 0; j < PER; ++j) {
+            const u32 sl = tid * PER + j;
+            if (sl <= HB_SLOTS) { toff[sl] = (u32)run | ((u32)(run >> 32) << 16); tfill[sl] = 0; }
+            if (cnt[j] >= 2) run += (u64)cnt[j] | (1ull << 32);
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 j = 0; j < EPT; ++j) {
+            const u32 i = tid + j * NT;
+            if (i >= size) break;
+            const u32 sl = eslot[i];
+            u32 r = 0;
+            if (((tcnt2[sl >> 1] >> (16 * (sl & 1))) & 0xFFFFu) >= 2) {
+                const u32 fill = atomicAdd(&tfill[sl], 1u);
+                const u32 t = toff[sl];
+                r = HB_KEPT | (fill == 0 ? HB_FIRST : 0u) | ((t >> 16) << 12) | ((t & 0xFFFFu) + fill);
+            }
+            rec[b0 + i] = r;
+        }
+        b = bn; b0 = n0; raw = nraw; size = nsize;
+#pragma unroll
+        for (u32 j = 0; j < EPT; ++j) mykey[j] = nkey[j];
+        __syncthreads();   // the table is rebuilt from here on
     }
 }
 
-// kept entries to their final places: bucket base (from the scan over the buckets) + place inside the bucket
+// kept entries to their final places: bucket base (exclusive scan over bsum) + place inside the bucket.
+// The places inside a bucket are a random permutation (slot order), so a bucket's output is put in
+// order in LDS and leaves in full lines.  One workgroup handles HB_EMIT consecutive buckets.
 template <class V>
-__global__ __launch_bounds__(256) void k_bucket_emit(const u32* __restrict__ rec, const V* __restrict__ vals,
-                                                     const u32* __restrict__ bstart, const u64* __restrict__ bbase,
-                                                     const u64* __restrict__ bsum, u32 nbuckets, V* __restrict__ vals2,
-                                                     u32* __restrict__ rank2, u32* __restrict__ first,
-                                                     u64* __restrict__ scal) {
-    const u32 b = blockIdx.x;
-    const u32 b0 = bstart[b], size = bstart[b + 1] - b0;
-    const u64 base = bbase[b];
-    const u32 ebase = (u32)base, kbase = (u32)(base >> 32);
-    for (u32 i = threadIdx.x; i < size; i += 256) {
-        const u32 r = rec[b0 + i];
-        if (r & HB_KEPT) {
-            const u32 p = ebase + (r & 0xFFFu), rk = kbase + ((r >> 12) & 0xFFFu);
-            vals2[p] = vals[b0 + i];
-            rank2[p] = rk;
-            if (r & HB_FIRST) first[rk] = p;
-        }
+__global__ __launch_bounds__(HB_THREADS) void k_bucket_emit(const u32* __restrict__ rec, const V* __restrict__ vals,
+                                                            const u32* __restrict__ bstart, const u64* __restrict__ bbase,
+                                                            const u64* __restrict__ bsum, u32 nbuckets,
+                                                            V* __restrict__ vals2, u32* __restrict__ rank2,
+                                                            u32* __restrict__ first, u64* __restrict__ scal) {
+    constexpr u32 NT = HB_THREADS, EPT = HB_CAP / NT;
+    __shared__ u32 s_start[HB_EMIT + 1];
+    __shared__ u64 s_base[HB_EMIT], s_sum[HB_EMIT];
+    __shared__ V o_tag[HB_CAP];
+    __shared__ unsigned short o_rank[HB_CAP], o_first[HB_CAP / 2];
+    const u32 tid = threadIdx.x;
+    const u32 g0 = blockIdx.x * HB_EMIT;
+    if (tid <= HB_EMIT) s_start[tid] = bstart[min(g0 + tid, nbuckets)];
+    if (tid < HB_EMIT) {
+        const bool in = g0 + tid < nbuckets;
+        s_base[tid] = in ? bbase[g0 + tid] : 0;
+        s_sum[tid] = in ? bsum[g0 + tid] : 0;
     }
-    if (b == nbuckets - 1 && threadIdx.x == 0) {
-        const u64 tot = base + bsum[b];
+    __syncthreads();
+    for (u32 q = 0; q < HB_EMIT; ++q) {
+        const u32 b0 = s_start[q], size = s_start[q + 1] - b0;
+        const u64 sum = s_sum[q];
+        if (sum == 0 || size > HB_CAP) continue;   // nothing kept (or a bucket the group kernel skipped)
+        u32 r[EPT];
+        V t[EPT];
+#pragma unroll
+        for (u32 j = 0; j < EPT; ++j) {
+            const bool in = tid + j * NT < size;
+            r[j] = in ? rec[b0 + tid + j * NT] : 0;
+            t[j] = in ? vals[b0 + tid + j * NT] : V(0);
+        }
+#pragma unroll
+        for (u32 j = 0; j < EPT; ++j) {
+            if (r[j] & HB_KEPT) {
+                const u32 place = r[j] & 0xFFFu, rk = (r[j] >> 12) & 0xFFFu;
+                o_tag[place] = t[j];
+                o_rank[place] = (unsigned short)rk;
+                if (r[j] & HB_FIRST) o_first[rk] = (unsigned short)place;
+            }
+        }
+        __syncthreads();
+        const u64 base = s_base[q];
+        const u32 ebase = (u32)base, kbase = (u32)(base >> 32), ke = (u32)sum, kk = (u32)(sum >> 32);
+        for (u32 i = tid; i < ke; i += NT) {
+            vals2[ebase + i] = o_tag[i];
+            rank2[ebase + i] = kbase + o_rank[i];
+        }
+        for (u32 i = tid; i < kk; i += NT) first[kbase + i] = ebase + o_first[i];
+        __syncthreads();
+    }
+    if (g0 + HB_EMIT >= nbuckets && tid == 0) {
+        const u64 tot = bbase[nbuckets - 1] + bsum[nbuckets - 1];
         scal[6] = (u32)tot;           // kept entries
         scal[2] = (u32)(tot >> 32);   // kept distinct keys (U)
         first[(u32)(tot >> 32)] = (u32)tot;   // sentinel
