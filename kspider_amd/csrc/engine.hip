@@ -288,7 +288,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     // grouping by hash bucket (see k_bucket_group): partition on the top pb key bits only — buckets of
     // 400-800 entries for uniform hashes (up to twice that when the keys span just over half of [0, 2^kbits))
     int pb = 0;
-    if (phase == 0 && !e->hash_off && !e->full_sort && kbits < 64 && nw >= 4096) {
+    // (bit ranges ending at bit 64: only far above the sizes at which the rocPRIM issue below shows)
+    if (phase == 0 && !e->hash_off && !e->full_sort && nw >= (kbits < 64 ? 4096u : (1u << 23))) {
         pb = 1;
         while ((nw >> pb) > HB_MEAN) ++pb;
         if (pb > kbits) pb = 0;   // (few distinct keys, many holders each: the sort path)
