@@ -282,14 +282,14 @@ __global__ void k_bucket_bounds(const u64* __restrict__ keys, u64 n, int shiftb,
 // Persistent workgroups, buckets b = blockIdx.x, += gridDim.x: while a bucket is grouped, the bounds
 // and then the keys of the workgroup's next bucket are already on their way (the kernel is a chain
 // of memory round trips otherwise).  bsum[] is zero at launch (trailing empty buckets are not visited).
-__global__ __launch_bounds__(HB_THREADS) void k_bucket_group(const u64* __restrict__ keys, const u32* __restrict__ bstart,
+__global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __restrict__ keys, const u32* __restrict__ bstart,
                                                              u32 nbuckets, u32 nw, u32* __restrict__ rec,
                                                              u64* __restrict__ bsum, u32* __restrict__ overflow) {
     constexpr u32 NT = HB_THREADS, NWV = NT / 64;
     __shared__ unsigned long long tkey[HB_SLOTS + 1];
     __shared__ u32 tcnt2[HB_SLOTS / 2 + 1];   // entries per key, two 16-bit counters per word
     __shared__ unsigned short eslot[HB_CAP];
-    __shared__ u64 wpart[NWV];
+    __shared__ u32 wpart[NWV];
     // after the inserts the keys are dead and their storage holds, per slot, the first place of the key's
     // entries | its rank << 16, and the fill cursor
     u32* toff = (u32*)tkey;
@@ -311,8 +311,10 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_group(const u64* __restri
         const u32 bn = b + gridDim.x;
         u32 n0 = nw, nraw = 0;          // bounds of the next bucket
         if (bn < nbuckets) { n0 = bstart[bn]; nraw = bstart[bn + 1] - n0; }
-        for (u32 i = tid; i <= HB_SLOTS; i += NT) tkey[i] = EMPTY;
-        for (u32 i = tid; i <= HB_SLOTS / 2; i += NT) tcnt2[i] = 0;
+        // the table is as large as the bucket needs (load at most 3/4 even if no two keys are equal)
+        const u32 slots = size <= 384 ? 512u : size <= 768 ? 1024u : size <= 1536 ? 2048u : HB_SLOTS;
+        for (u32 i = tid; i <= slots; i += NT) tkey[i] = EMPTY;
+        for (u32 i = tid; i <= slots / 2; i += NT) tcnt2[i] = 0;
         __syncthreads();
 #pragma unroll
         for (u32 j = 0; j < EPT; ++j) {
@@ -321,13 +323,13 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_group(const u64* __restri
             const unsigned long long key = mykey[j];
             u32 h;
             if (key == EMPTY) {
-                h = HB_SLOTS;   // the one key that looks like an empty slot has a slot of its own
+                h = slots;   // the one key that looks like an empty slot has a slot of its own
             } else {
-                h = (u32)((key * 0x9E3779B97F4A7C15ull) >> 52) & (HB_SLOTS - 1);
+                h = (u32)((key * 0x9E3779B97F4A7C15ull) >> 52) & (slots - 1);
                 while (true) {
                     const unsigned long long prev = atomicCAS(&tkey[h], EMPTY, key);
                     if (prev == EMPTY || prev == key) break;
-                    h = (h + 1) & (HB_SLOTS - 1);
+                    h = (h + 1) & (slots - 1);
                 }
             }
             eslot[i] = (unsigned short)h;
@@ -338,27 +340,31 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_group(const u64* __restri
 #pragma unroll
         for (u32 j = 0; j < EPT; ++j) nkey[j] = tid + j * NT < nsize ? keys[n0 + tid + j * NT] : 0;
         __syncthreads();
-        // exclusive scan over the slots of (kept entries | kept keys << 32): 9 slots per thread
+        // exclusive scan over the slots of (kept entries | kept keys << 16): up to 9 slots per thread
+        const u32 per = slots / NT + 1;
         u32 cnt[PER];
-        u64 mine = 0;
+        u32 mine = 0;
 #pragma unroll
         for (u32 j = 0; j < PER; ++j) {
-            const u32 sl = tid * PER + j;
-            cnt[j] = sl <= HB_SLOTS ? (tcnt2[sl >> 1] >> (16 * (sl & 1))) & 0xFFFFu : 0;
-            if (cnt[j] >= 2) mine += (u64)cnt[j] | (1ull << 32);
+            const u32 sl = tid * per + j;
+            cnt[j] = j < per && sl <= slots ? (tcnt2[sl >> 1] >> (16 * (sl & 1))) & 0xFFFFu : 0;
+            if (cnt[j] >= 2) mine += cnt[j] | (1u << 16);
         }
-        u64 inc = mine;
-        for (int o = 1; o < 64; o <<= 1) { const u64 up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+        u32 inc = mine;
+        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if (lane >= o) inc += up; }
         if (lane == 63) wpart[wv] = inc;
         __syncthreads();
-        u64 run = inc - mine;
+        u32 run = inc - mine;
         for (int w = 0; w < wv; ++w) run += wpart[w];
-        if (tid == NT - 1) bsum[b] = run + mine;   // the last thread's inclusive sum: the bucket's total
+        if (tid == NT - 1) {   // the last thread's inclusive sum: the bucket's total
+            const u32 tot = run + mine;
+            bsum[b] = (u64)(tot & 0xFFFFu) | ((u64)(tot >> 16) << 32);
+        }
 #pragma unroll
         for (u32 j = 0; j < PER; ++j) {
-            const u32 sl = tid * PER + j;
-            if (sl <= HB_SLOTS) { toff[sl] = (u32)run | ((u32)(run >> 32) << 16); tfill[sl] = 0; }
-            if (cnt[j] >= 2) run += (u64)cnt[j] | (1ull << 32);
+            const u32 sl = tid * per + j;
+            if (j < per && sl <= slots) { toff[sl] = run; tfill[sl] = 0; }
+            if (cnt[j] >= 2) run += cnt[j] | (1u << 16);
         }
         __syncthreads();
 #pragma unroll
