@@ -143,6 +143,15 @@ namespace ksp {
 
 static inline unsigned grid_for(u64 n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
+// The label pass looks at one key in (result + 1): ~64 sampled shared keys per source say as much about a
+// source's relatives as all of them (sources with thousands of shared keys are the common case).
+static u32 label_sampling(u64 kept_entries, u32 n_sources) {
+    const u64 per_source = kept_entries / std::max<u32>(1, n_sources);
+    u32 every = 1;
+    while (every < 64 && per_source / (2 * every) >= 64) every *= 2;
+    return every - 1;
+}
+
 template <class V>
 static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStream_t st, const int phase) {
     constexpr bool W = std::is_same<V, u64>::value;   // weighted: 64-bit tags carry the key's weight
@@ -187,6 +196,16 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     const bool reorder = e->reorder;
     u32 label_max = std::max<u32>(256, N / 16);   // holders above which a key is ignored by the label pass
     if (const char* lm = std::getenv("KSP_DEBUG_LABEL_MAX")) label_max = (u32)std::max(1, std::atoi(lm));
+    // the label pass over the kept keys (first[] = where each key's entries start); KB is free whenever it runs
+    auto run_label = [&](const u32* firstp, const u32 n_keys, const u64 kept) {
+        const u32 skip = label_sampling(kept, N);
+        const int ls = e->KB.bytes >= (size_t)N * 128 ? 5 : 0;
+        u32* lab = ls ? (u32*)e->KB.p : label;
+        if (ls) hipLaunchKernelGGL(k_label_spread, dim3(grid_for(N, bs)), dim3(bs), 0, st, lab, ls, N);
+        hipLaunchKernelGGL((k_label<V>), dim3(grid_for(n_keys / (skip + 1) + 1, bs)), dim3(bs), 0, st, VA, firstp, lab, ls,
+                           skip, label_max, n_keys);
+        if (ls) hipLaunchKernelGGL(k_label_gather, dim3(grid_for(N, bs)), dim3(bs), 0, st, lab, ls, label, N);
+    };
     int bbits = 1;
     while ((1u << bbits) < nb) ++bbits;
     size_t tb = 0;
@@ -209,9 +228,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             KSP_HIP(hipMemcpyAsync(scal + 2, e->h_scal + 2, 8, hipMemcpyHostToDevice, st));
         }
         if (reorder) {
-            const u32 skip = m / std::max<u32>(1, N) >= 512 ? 7u : 0u;
-            hipLaunchKernelGGL((k_label<V>), dim3(grid_for(nk, bs)), dim3(bs), 0, st, VA, e->post_off, label, skip,
-                               label_max, nk);
+            run_label(e->post_off, nk, m);
         } else {
             hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
         }
@@ -377,10 +394,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if (m == 0 && phase == 0) return KSP_OK;   // no key is shared by two sources: no pair at all
     if (reorder && m) {
         // label = smallest source id among the holders of a source's shared keys
-        // (sources with hundreds of shared keys: every 8th key says as much about a source's relatives as all)
-        const u32 skip = m / std::max<u32>(1, N) >= 512 ? 7u : 0u;
-        const u32 U = (u32)e->h_scal[2];
-        hipLaunchKernelGGL((k_label<V>), dim3(grid_for(U, bs)), dim3(bs), 0, st, VA, first, label, skip, label_max, U);
+        run_label(first, (u32)e->h_scal[2], m);
     }
     if (phase == 1) return KSP_OK;
     }   // phase != 2
@@ -393,7 +407,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         if ((rc = e->tmp.ensure(tb))) return rc;
         KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, label, labs, iota, order, (size_t)N, 0, lbits, st));
         hipLaunchKernelGGL(k_perm, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, newidx, N);
-        if (m) hipLaunchKernelGGL((k_retag<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, VA, newidx, m);
+        if (m) hipLaunchKernelGGL((k_retag<V>), dim3(grid_for(m / (16 / sizeof(V)) + 1, bs)), dim3(bs), 0, st, VA, newidx, m);
         hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
     }
     if (m == 0) return KSP_OK;
@@ -407,27 +421,29 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     // now: rk2 = ranks sorted by (block, rank); VB = tags in the same order.  KB, VA, R1 are free.
     V* T = VB;
     u32* flag = (u32*)VA;
-    u32* didx = (u32*)e->KB.p;             // m
-    u32* estart = (u32*)e->KB.p + (n + 2); // up to m+1
+    u32* grank = (u32*)e->KB.p;            // rank of every (block, key) group (up to m)
+    u32* estart = (u32*)e->KB.p + (n + 2); // first entry of every group (up to m+1)
     const HeadFn<V> head{rk2, T};
     auto hf = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u64>(0), head);
-    tb = 0;
-    KSP_HIP(rocprim::exclusive_scan(nullptr, tb, hf, didx, (u32)0, m, rocprim::plus<u32>(), st));
-    if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, hf, didx, (u32)0, m, rocprim::plus<u32>(), st));
-    hipLaunchKernelGGL((k_ktot<V>), dim3(1), dim3(64), 0, st, head, didx, estart, scal, m);
-    hipLaunchKernelGGL((k_blk_raw<V>), dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, T, didx, scal, blk_raw, nb, m);
-    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, blk_raw, blk_pos, scal, nb);
-    hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
-    hipLaunchKernelGGL((k_emit_keys<V>), dim3(grid_for(m, bs)), dim3(bs), 0, st, rk2, T, head, didx, blk_raw,
-                       blk_pos, e->bkeys.as<u32>(), estart, m);
+    {
+        HeadScatterIt<V> out{{head, estart, grank, scal, m}, 0};
+        tb = 0;
+        KSP_HIP(rocprim::inclusive_scan(nullptr, tb, hf, out, m, rocprim::plus<u32>(), st));
+        if ((rc = e->tmp.ensure(tb))) return rc;
+        KSP_HIP(rocprim::inclusive_scan(e->tmp.p, tb, hf, out, m, rocprim::plus<u32>(), st));
+    }
     // the number of distinct (block, key) groups sizes the posting passes (after the source reordering it is
     // an order of magnitude below the entry count: one 8-byte read-back pays for itself)
     KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 8, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL((k_blk_raw<V>), dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, T, estart, scal, blk_raw, nb, m);
+    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, blk_raw, blk_pos, scal, nb);
+    hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
     KSP_HIP(hipStreamSynchronize(st));
     const u64 K = std::max<u64>(1, e->h_scal[1]);
     u32* mmsz = flag;                      // (VA is free: the head flags are computed on the fly)
-    u32* mmoff = (u32*)KA;                 // rk2 is dead after k_emit_keys
+    u32* mmoff = (u32*)KA;                 // rk2 is dead after the head scan
+    hipLaunchKernelGGL((k_emit_keys<V>), dim3(grid_for(K, bs)), dim3(bs), 0, st, grank, T, estart, blk_raw, blk_pos,
+                       e->bkeys.as<u32>(), e->h_scal[1]);
     hipLaunchKernelGGL(k_bigflag, dim3(grid_for(K, bs)), dim3(bs), 0, st, estart, scal, mmsz, K);
     tb = 0;
     KSP_HIP(rocprim::exclusive_scan(nullptr, tb, mmsz, mmoff, (u32)0, K, rocprim::plus<u32>(), st));

@@ -61,9 +61,9 @@ __global__ void k_iota(u32* __restrict__ p, u32 n) {
 __device__ inline u32 src_of_tag(u32 t) { return (t >> 8) * TB + (t & 0xFFu); }
 template <class V>
 __global__ void k_label(const V* __restrict__ vals, const u32* __restrict__ first, u32* __restrict__ label,
-                        const u32 skip, const u32 max_holders, u32 n_keys) {
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per kept key
-    if (r >= n_keys || (r & skip)) return;
+                        const int lshift, const u32 skip, const u32 max_holders, u32 n_keys) {
+    const u32 r = (blockIdx.x * blockDim.x + threadIdx.x) * (skip + 1);   // one thread per sampled key (skip = 2^k - 1)
+    if (r >= n_keys) return;
     const u32 f0 = first[r], f1 = first[r + 1];   // (first[] has a sentinel: first[U] = number of entries)
     // a key held by very many sources says nothing about who is related to whom — it would only pull
     // unrelated clusters under one label
@@ -72,8 +72,18 @@ __global__ void k_label(const V* __restrict__ vals, const u32* __restrict__ firs
     for (u32 e = f0; e < f1; ++e) mn = min(mn, src_of_tag(tag_of(vals[e])));
     for (u32 e = f0; e < f1; ++e) {
         const u32 s = src_of_tag(tag_of(vals[e]));
-        if (mn < label[s]) atomicMin(&label[s], mn);
+        if (mn < label[(size_t)s << lshift]) atomicMin(&label[(size_t)s << lshift], mn);
     }
+}
+// While they are being lowered the labels sit on memory lines of their own (label s at index s << lshift):
+// atomics on one 128-byte line are served one at a time, and a few thousand sources share a few hundred lines.
+__global__ void k_label_spread(u32* __restrict__ wide, const int lshift, u32 n) {
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) wide[(size_t)s << lshift] = s;
+}
+__global__ void k_label_gather(const u32* __restrict__ wide, const int lshift, u32* __restrict__ label, u32 n) {
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) label[s] = wide[(size_t)s << lshift];
 }
 // Postings input (an inverted index: per key its holders, e.g. the reference's colour -> sources map):
 // the state stage 1 reaches after sorting and pruning, written directly — entry tags, the key index as
@@ -101,11 +111,27 @@ __global__ void k_perm(const u32* __restrict__ order, u32* __restrict__ newidx, 
 }
 template <class V>
 __global__ void k_retag(V* __restrict__ vals, const u32* __restrict__ newidx, u64 n) {
-    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const V v = vals[e];
-    const u32 ni = newidx[src_of_tag(tag_of(v))];
-    vals[e] = make_tag<V>(((ni / TB) << 8) | (ni % TB), weight_of(v));
+    // 16 bytes of tags per thread (2-byte tags one at a time leave most of every memory transaction unused)
+    constexpr u32 VEC = 16 / sizeof(V);
+    union Pack { uint4 q; V v[VEC]; };
+    const u64 e0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+    if (e0 >= n) return;
+    if (e0 + VEC <= n) {
+        Pack p;
+        p.q = *reinterpret_cast<const uint4*>(vals + e0);
+#pragma unroll
+        for (u32 j = 0; j < VEC; ++j) {
+            const u32 ni = newidx[src_of_tag(tag_of(p.v[j]))];
+            p.v[j] = make_tag<V>(((ni / TB) << 8) | (ni % TB), weight_of(p.v[j]));
+        }
+        *reinterpret_cast<uint4*>(vals + e0) = p.q;
+    } else {
+        for (u64 e = e0; e < n; ++e) {
+            const V v = vals[e];
+            const u32 ni = newidx[src_of_tag(tag_of(v))];
+            vals[e] = make_tag<V>(((ni / TB) << 8) | (ni % TB), weight_of(v));
+        }
+    }
 }
 // per block (of the new order): the largest per-source bound
 __global__ void k_blk_bound(const u32* __restrict__ src_bound, const u32* __restrict__ newidx, u32* __restrict__ blk_max,
@@ -522,21 +548,50 @@ struct HeadFn {
     }
 };
 
-// scal[1] = Ktot (distinct (block, key) groups), estart[Ktot] = n.
+// Output "iterator" of the inclusive scan over the head flags: the store of element e records, for a head,
+// where its (block, key) group starts and the group's rank — the prefix sums themselves are never written.
+// The last element leaves scal[1] = Ktot (distinct (block, key) groups) and estart[Ktot] = n.
 template <class V>
-__global__ void k_ktot(const HeadFn<V> head, const u32* __restrict__ didx, u32* __restrict__ estart,
-                       u64* __restrict__ scal, u64 n) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        u32 k = didx[n - 1] + head(n - 1);
-        estart[k] = (u32)n;
-        scal[1] = k;
-    }
-}
+struct HeadScatterIt {
+    using iterator_category = std::random_access_iterator_tag;
+    using value_type = u32;
+    using difference_type = std::ptrdiff_t;
+    using pointer = void;
+    struct Ctx {
+        HeadFn<V> head;
+        u32* estart;
+        u32* grank;
+        u64* scal;
+        u64 n;
+    };
+    struct Ref {
+        Ctx c;
+        u64 e;
+        __device__ const Ref& operator=(const u32 cur) const {
+            if (c.head(e)) {
+                c.estart[cur - 1] = (u32)e;
+                c.grank[cur - 1] = c.head.rk[e];
+            }
+            if (e == c.n - 1) {
+                c.scal[1] = cur;
+                c.estart[cur] = (u32)c.n;
+            }
+            return *this;
+        }
+    };
+    using reference = Ref;
+    Ctx c;
+    u64 base;
+    __host__ __device__ HeadScatterIt operator+(const std::ptrdiff_t d) const { return HeadScatterIt{c, base + (u64)d}; }
+    __host__ __device__ HeadScatterIt& operator+=(const std::ptrdiff_t d) { base += (u64)d; return *this; }
+    __device__ Ref operator[](const std::ptrdiff_t i) const { return Ref{c, base + (u64)i}; }
+    __device__ Ref operator*() const { return Ref{c, base}; }
+};
 
 // raw (unpadded) first distinct-key index of each block: entries are sorted by block, so the
 // first entry of block b is found by bisection over the tags.
 template <class V>
-__global__ void k_blk_raw(const V* __restrict__ vals, const u32* __restrict__ didx, const u64* __restrict__ scal,
+__global__ void k_blk_raw(const V* __restrict__ vals, const u32* __restrict__ estart, const u64* __restrict__ scal,
                           u32* __restrict__ blk_raw, u32 nb, u64 n) {
     u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nb) return;
@@ -545,7 +600,13 @@ __global__ void k_blk_raw(const V* __restrict__ vals, const u32* __restrict__ di
         u64 mid = lo + ((hi - lo) >> 1);
         if ((tag_of(vals[mid]) >> 8) < b) lo = mid + 1; else hi = mid;
     }
-    blk_raw[b] = (lo < n) ? didx[lo] : (u32)scal[1];
+    // the block's first group: the first one that starts at or after the block's first entry
+    u32 glo = 0, ghi = (u32)scal[1];
+    while (glo < ghi) {
+        const u32 mid = glo + ((ghi - glo) >> 1);
+        if (estart[mid] < lo) glo = mid + 1; else ghi = mid;
+    }
+    blk_raw[b] = glo;
 }
 
 // Padded layout of the block lists: every list starts at a multiple of 4 entries and is
@@ -577,18 +638,15 @@ __global__ void k_fill(u32* __restrict__ p, u32 v, u64 n) {
     if (i < n) p[i] = v;
 }
 
-// distinct ranks of every block (padded layout) + first entry of each group.
+// distinct ranks of every block, from the dense group list to the padded layout.
 template <class V>
-__global__ void k_emit_keys(const u32* __restrict__ rk, const V* __restrict__ vals, const HeadFn<V> head,
-                            const u32* __restrict__ didx, const u32* __restrict__ blk_raw,
-                            const u32* __restrict__ blk_pos, u32* __restrict__ brk, u32* __restrict__ estart, u64 n) {
-    u64 e = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    if (head(e)) {
-        u32 d = didx[e], b = tag_of(vals[e]) >> 8;
-        brk[blk_pos[b] + (d - blk_raw[b])] = rk[e];
-        estart[d] = (u32)e;
-    }
+__global__ void k_emit_keys(const u32* __restrict__ grank, const V* __restrict__ vals, const u32* __restrict__ estart,
+                            const u32* __restrict__ blk_raw, const u32* __restrict__ blk_pos, u32* __restrict__ brk,
+                            u64 n_groups) {
+    const u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_groups) return;
+    const u32 b = tag_of(vals[estart[d]]) >> 8;
+    brk[blk_pos[b] + ((u32)d - blk_raw[b])] = grank[d];
 }
 
 __global__ void k_bigflag(const u32* __restrict__ estart, const u64* __restrict__ scal, u32* __restrict__ big,
