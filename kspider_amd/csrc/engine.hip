@@ -109,6 +109,9 @@ struct ksp_engine {
     bool full_sort = false;       // keys defeat the 32-bit prefix sort: use all bits
     bool hash_off = false;        // keys defeat the bucket grouping (a bucket overflowed): use the sort path
     u32 hb_slots = 0;             // workgroups of k_bucket_group the device holds at once
+    bool key_groups_off = false;  // a key has too many holders for the key-by-key list build: sort the entries by block
+    bool have_rank_pairs = false; // gp holds (block, rank) of every list word in rank order (key-by-key build)
+    ksp::Buf gp;
     bool reorder = true;          // order the sources by shared-key label before cutting blocks (KSP_REORDER=0: off)
     bool need32 = false;          // some tile pairs two blocks that both hold a source with >= 2^16 k-mers
     int key_bits = 64;
@@ -407,10 +410,61 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         if ((rc = e->tmp.ensure(tb))) return rc;
         KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, label, labs, iota, order, (size_t)N, 0, lbits, st));
         hipLaunchKernelGGL(k_perm, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, newidx, N);
-        if (m) hipLaunchKernelGGL((k_retag<V>), dim3(grid_for(m / (16 / sizeof(V)) + 1, bs)), dim3(bs), 0, st, VA, newidx, m);
         hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
     }
     if (m == 0) return KSP_OK;
+    e->have_rank_pairs = false;
+    // ---- the block lists, key by key (see k_key_groups) ------------------------------------------------
+    if (!e->key_groups_off && m < (1ull << 32) - KG_CHUNK) {
+        const u32 U = (u32)e->h_scal[2];
+        const u32* firstp = phase == 3 ? e->post_off : (const u32*)e->FK.p;   // where each key's entries start (sentinel at U)
+        u64* gsum = (u64*)KA;                 // per key: groups | masks << 32   (KA: the sorted keys are dead)
+        u64* goff = gsum + (U + 2);
+        u32* d_kovf = (u32*)(scal + 11);
+        const u32 chunks = (u32)((m + KG_CHUNK - 1) / KG_CHUNK);
+        KSP_HIP(hipMemsetAsync(d_kovf, 0, 8, st));
+        KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input — are visited by no chunk)
+        hipLaunchKernelGGL((k_key_groups<V, 0, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, rank1, firstp, newidx, (u32)m, U,
+                           gsum, (const u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32*)nullptr, (uint4*)nullptr,
+                           (u32*)nullptr, d_kovf);
+        tb = 0;
+        KSP_HIP(rocprim::exclusive_scan(nullptr, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
+        if ((rc = e->tmp.ensure(tb))) return rc;
+        KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
+        hipLaunchKernelGGL(k_group_totals, dim3(1), dim3(64), 0, st, gsum, goff, scal, U);
+        // the number of groups sizes everything after (one 8-byte read-back pays for itself)
+        KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 8, hipMemcpyDeviceToHost, st));
+        KSP_HIP(hipMemcpyAsync(e->h_scal + 11, scal + 11, 8, hipMemcpyDeviceToHost, st));
+        KSP_HIP(hipStreamSynchronize(st));
+        if ((u32)e->h_scal[11]) {
+            e->key_groups_off = true;   // a key with thousands of holders: this engine sorts by block from now on
+        } else {
+            const u64 K = std::max<u64>(1, e->h_scal[1]);
+            if ((rc = e->gp.ensure((K + 4) * 12))) return rc;
+            u32 *rec_blk = e->gp.as<u32>(), *rec_rank = rec_blk + (K + 4), *sblk = rec_rank + (K + 4);
+            u64* rec_val = (u64*)e->KB.p;     // (KB: free since the grouping by key)
+            u64* sval = (u64*)KA;             // (the per-key counts and offsets are dead once the records are written)
+            u32* wkey = W ? (u32*)VB : nullptr;   // (VB: the partitioned tags are dead)
+            hipLaunchKernelGGL((k_key_groups<V, 1, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, rank1, firstp, newidx, (u32)m,
+                               U, (u64*)nullptr, goff, rec_blk, rec_val, rec_rank, e->mm.as<uint4>(), wkey, d_kovf);
+            tb = 0;
+            KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
+            if ((rc = e->tmp.ensure(tb))) return rc;
+            KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
+            hipLaunchKernelGGL(k_blk_raw_groups, dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, sblk, (u32)e->h_scal[1], blk_raw, nb);
+            hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, blk_raw, blk_pos, scal, nb);
+            hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
+            hipLaunchKernelGGL((k_place_groups<W>), dim3(grid_for(K, bs)), dim3(bs), 0, st, sblk, sval, blk_raw, blk_pos, wkey,
+                               e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, (u32)e->h_scal[1]);
+            hipLaunchKernelGGL(k_cidx, dim3(grid_for((u64)nb * (e->ncell + 1), bs)), dim3(bs), 0, st, e->bkeys.as<u32>(),
+                               blk_raw, blk_pos, scal, e->part.as<u32>(), nb, e->ncell);
+            KSP_HIP(hipGetLastError());
+            e->have_rank_pairs = true;   // rec_rank / rec_blk: (rank, block) of every list word in rank order
+            return KSP_OK;
+        }
+    }
+    // ---- the block lists by sorting the entries by block -------------------------------------------------
+    if (reorder) hipLaunchKernelGGL((k_retag<V>), dim3(grid_for(m / (16 / sizeof(V)) + 1, bs)), dim3(bs), 0, st, VA, newidx, m);
     // sort 2: stable by block id (bits [8, 8+bbits) of the tag), payload = rank:  VA,rank1 -> VB,rk2
     u32* rk2 = (u32*)KA;                   // KA (sorted keys) is dead from here on
     tb = 0;
@@ -483,9 +537,13 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     const size_t bit_words = (size_t)(((T + 63) / 64) * 2 + 2);
     if ((rc = e->tbits.ensure(bit_words * 4 + T + 64))) return rc;   // packed bitmap, then one flag byte per tile
     if ((rc = e->dwork.ensure(((size_t)nb + 2) * 8))) return rc;
-    if ((rc = e->KA.ensure((K + 4) * 8))) return rc;
-    if ((rc = e->KB.ensure((K + 4) * 8))) return rc;
-    u32 *pr = (u32*)e->KA.p, *pb = pr + (K + 4), *pr2 = (u32*)e->KB.p, *pb2 = pr2 + (K + 4);
+    const bool ranked = e->have_rank_pairs;   // the key-by-key build left the pairs in rank order: nothing to sort
+    if (!ranked) {
+        if ((rc = e->KA.ensure((K + 4) * 8))) return rc;
+        if ((rc = e->KB.ensure((K + 4) * 8))) return rc;
+    }
+    u32 *pr = ranked ? nullptr : (u32*)e->KA.p, *pb = ranked ? nullptr : pr + (K + 4);
+    u32 *pr2 = ranked ? e->gp.as<u32>() + (K + 4) : (u32*)e->KB.p, *pb2 = ranked ? e->gp.as<u32>() : pr2 + (K + 4);
     unsigned char* flags = (unsigned char*)e->tbits.p + bit_words * 4;
     KSP_HIP(hipMemsetAsync(e->tbits.p, 0, bit_words * 4 + T + 64, st));
     KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
@@ -493,12 +551,14 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     hipLaunchKernelGGL(k_list_pairs, dim3(nb, shares), dim3(256), 0, st, e->bkeys.as<u32>(), e->info.as<u32>(),
                        e->mm.as<uint4>(), e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), pr, pb,
                        e->dwork.as<unsigned long long>());
-    int rbits = 1;
-    while (rbits < 32 && (U >> rbits)) ++rbits;
-    size_t tb = 0;
-    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, pr, pr2, pb, pb2, (size_t)K, 0, rbits, st));
-    if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, pr, pr2, pb, pb2, (size_t)K, 0, rbits, st));
+    if (!ranked) {
+        int rbits = 1;
+        while (rbits < 32 && (U >> rbits)) ++rbits;
+        size_t tb = 0;
+        KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, pr, pr2, pb, pb2, (size_t)K, 0, rbits, st));
+        if ((rc = e->tmp.ensure(tb))) return rc;
+        KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, pr, pr2, pb, pb2, (size_t)K, 0, rbits, st));
+    }
     hipLaunchKernelGGL(k_tile_flags, dim3(grid_for(K, 256)), dim3(256), 0, st, pr2, pb2, K, nb, flags);
     hipLaunchKernelGGL(k_pack_flags, dim3(grid_for(T, 256)), dim3(256), 0, st, flags, T, e->tbits.as<u32>());
     // results to pinned host memory in stream order: the caller's end-of-build synchronisation covers them
@@ -556,7 +616,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
-                        &e->d_wg};
+                        &e->d_wg, &e->gp};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
@@ -702,6 +762,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     e->h_off.assign(h_offsets, h_offsets + n_sources + 1);
     if (std::getenv("KSP_FULL_SORT")) e->full_sort = true;   // diagnostic: sort on all key bits
     if (const char* hg = std::getenv("KSP_HASH_GROUP")) e->hash_off = std::atoi(hg) == 0;   // diagnostic / tests
+    if (const char* kg = std::getenv("KSP_KEY_GROUPS")) e->key_groups_off = std::atoi(kg) == 0;
     e->st = ksp_stats{};
     e->st.n_sources = n_sources;
     e->st.n_entries = n;
@@ -1011,6 +1072,7 @@ int ksp_engine_assemble(ksp_engine* e, uint32_t nparts, const uint64_t* h_sizes 
     KSP_HIP(hipGetLastError());
     e->h_scal_words = ktot;
     e->h_scal_keys = utot;
+    e->have_rank_pairs = false;   // (the assembled lists: pairs from the lists themselves)
     if ((rc = launch_sched_kernels(e, st))) return rc;
     KSP_HIP(hipEventRecord(e->ev[1], st));
     KSP_HIP(hipStreamSynchronize(st));

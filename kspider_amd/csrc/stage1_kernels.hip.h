@@ -536,6 +536,126 @@ struct PruneScatterIt {
     __device__ Ref operator*() const { return Ref{c, base}; }
 };
 
+// ---- (block, key) groups straight from the keys --------------------------------------------------
+// After the grouping by key the entries of a key are contiguous (first[]), and after the source
+// reordering nearly all of a key's holders sit in one block: the (block, key) groups — the words of
+// the block lists — can be read off key by key, and only the *groups* (an order of magnitude fewer than
+// the entries) have to be brought into block order.  Two passes over the entries (count, then emit):
+// a workgroup stages a chunk of entries in LDS as new source indices, one thread per key walks its
+// holders block by block (ascending), building the 128-bit membership mask of each group.
+// Pass 0 leaves per key (groups | groups with more than INLINE_MAX members << 32); pass 1 writes, at the
+// scanned offsets, the group records in rank order: block, rank << 32 | posting word, and the masks.
+// Keys with more than KG_MAXC holders do not fit the staging: they raise *ovf and the build takes the
+// sort-by-block path instead.
+constexpr u32 KG_CHUNK = 4096, KG_MAXC = 2048, KG_THREADS = 256;
+
+template <class V, int PASS, bool W>
+__global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__ vals, const u32* __restrict__ rank,
+                                                           const u32* __restrict__ first, const u32* __restrict__ newidx,
+                                                           u32 m, u32 n_keys, u64* __restrict__ gsum,
+                                                           const u64* __restrict__ goff, u32* __restrict__ rec_blk,
+                                                           u64* __restrict__ rec_val, u32* __restrict__ rec_rank,
+                                                           uint4* __restrict__ bigmask, u32* __restrict__ wkey,
+                                                           u32* __restrict__ ovf) {
+    __shared__ u32 s_idx[KG_CHUNK + KG_MAXC];
+    const u32 E0 = blockIdx.x * KG_CHUNK, E1 = min(m, E0 + KG_CHUNK);
+    // the keys that start inside [E0, E1)
+    u32 r_lo = rank[E0];
+    if (first[r_lo] != E0) ++r_lo;
+    u32 r_hi = n_keys;
+    if (E1 < m) { r_hi = rank[E1]; if (first[r_hi] != E1) ++r_hi; }
+    if (r_lo >= r_hi) return;
+    const u32 Eend = min(first[r_hi], E0 + KG_CHUNK + KG_MAXC);
+    for (u32 i = threadIdx.x; E0 + i < Eend; i += KG_THREADS) s_idx[i] = newidx[src_of_tag(tag_of(vals[E0 + i]))];
+    __syncthreads();
+    for (u32 r = r_lo + threadIdx.x; r < r_hi; r += KG_THREADS) {
+        const u32 fa = first[r], c = first[r + 1] - fa, f0 = fa - E0;
+        if (c > KG_MAXC) {
+            *ovf = 1;
+            if (PASS == 0) gsum[r] = 0;
+            continue;
+        }
+        u32 cur = ~0u;
+        for (u32 i = 0; i < c; ++i) cur = min(cur, s_idx[f0 + i] / TB);
+        u32 groups = 0, bigs = 0;
+        u64 base = 0;
+        if (PASS == 1) {
+            base = goff[r];
+            if (W) wkey[r] = weight_of(vals[fa]);
+        }
+        while (cur != ~0u) {
+            u32 nxt = ~0u;
+            unsigned long long lo = 0, hi = 0;
+            for (u32 i = 0; i < c; ++i) {
+                const u32 t = s_idx[f0 + i], b = t / TB;
+                if (b == cur) {
+                    const u32 l = t % TB;
+                    if (l < 64) lo |= 1ull << l; else hi |= 1ull << (l - 64);
+                } else if (b > cur && b < nxt) nxt = b;
+            }
+            const u32 cnt = __popcll(lo) + __popcll(hi);
+            if (PASS == 1) {
+                u32 inf;
+                if (cnt <= INLINE_MAX) {
+                    inf = (cnt - 1) << 29;
+                    unsigned long long a = lo, bq = hi;
+                    for (u32 j = 0; j < cnt; ++j) {   // local ids, ascending, 7 bits each
+                        u32 id;
+                        if (a) { id = __ffsll((long long)a) - 1; a &= a - 1; }
+                        else { id = 64 + __ffsll((long long)bq) - 1; bq &= bq - 1; }
+                        inf |= id << (7 * j);
+                    }
+                } else {
+                    const u32 o = (u32)(base >> 32) + bigs;
+                    bigmask[o] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+                    inf = BIG | o;
+                }
+                const u32 g = (u32)base + groups;
+                rec_blk[g] = cur;
+                rec_val[g] = ((u64)r << 32) | inf;
+                rec_rank[g] = r;
+            }
+            ++groups;
+            bigs += cnt > INLINE_MAX;
+            cur = nxt;
+        }
+        if (PASS == 0) gsum[r] = (u64)groups | ((u64)bigs << 32);
+    }
+}
+// totals of the group scan: scal[1] = list words (groups), scal[7] = masks
+__global__ void k_group_totals(const u64* __restrict__ gsum, const u64* __restrict__ goff, u64* __restrict__ scal, u32 n_keys) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const u64 t = goff[n_keys - 1] + gsum[n_keys - 1];
+        scal[1] = (u32)t;
+        scal[7] = t >> 32;
+    }
+}
+// first group of every block in the block-sorted group list
+__global__ void k_blk_raw_groups(const u32* __restrict__ sblk, u32 n_groups, u32* __restrict__ blk_raw, u32 nb) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > nb) return;
+    u32 lo = 0, hi = n_groups;
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (sblk[mid] < b) lo = mid + 1; else hi = mid;
+    }
+    blk_raw[b] = lo;
+}
+// groups (sorted by block, ranks ascending inside a block) to the padded lists
+template <bool W>
+__global__ void k_place_groups(const u32* __restrict__ sblk, const u64* __restrict__ sval, const u32* __restrict__ blk_raw,
+                               const u32* __restrict__ blk_pos, const u32* __restrict__ wkey, u32* __restrict__ brk,
+                               u32* __restrict__ info, u32* __restrict__ bw, u32 n_groups) {
+    const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_groups) return;
+    const u32 b = sblk[d];
+    const u64 v = sval[d];
+    const u32 dst = blk_pos[b] + (d - blk_raw[b]);
+    brk[dst] = (u32)(v >> 32);
+    info[dst] = (u32)v;
+    if (W) bw[dst] = wkey[(u32)(v >> 32)];
+}
+
 // 1 when entry e opens a new (block, rank) group; evaluated on the fly by the scan and the passes after it
 // (two neighbouring loads of two arrays) instead of being written out by a pass of its own
 template <class V>
@@ -723,8 +843,10 @@ __global__ void k_list_pairs(const u32* __restrict__ brk, const u32* __restrict_
     const u32 i0 = (u32)(((u64)cnt * blockIdx.y) / gridDim.y), i1 = (u32)(((u64)cnt * (blockIdx.y + 1)) / gridDim.y);
     unsigned long long acc = 0, holders = 0;
     for (u32 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        pr[dst + i] = brk[src + i];
-        pb[dst + i] = b;
+        if (pr) {   // (the key-by-key build already has its pairs in rank order)
+            pr[dst + i] = brk[src + i];
+            pb[dst + i] = b;
+        }
         const u32 inf = info[src + i];
         u32 c;
         if (inf >= BIG) { const uint4 m = bigmask[inf & ~BIG]; c = __popc(m.x) + __popc(m.y) + __popc(m.z) + __popc(m.w); }
@@ -746,7 +868,8 @@ __global__ void k_tile_flags(const u32* __restrict__ pr, const u32* __restrict__
     if (i >= n) return;
     const u32 r = pr[i], I = pb[i];
     for (u64 j = i + 1; j < n && pr[j] == r; ++j) {   // (stable sort: blocks ascend inside a key)
-        const u64 t = tile_row_start_dev(I, nb) + (pb[j] - I);
+        const u32 J = pb[j], A = min(I, J), B = max(I, J);
+        const u64 t = tile_row_start_dev(A, nb) + (B - A);
         if (!flags[t]) flags[t] = 1;
     }
 }

@@ -9,7 +9,8 @@ from kspider_amd import engine, synth
 pytestmark = pytest.mark.gpu
 
 MODES = [{}, {"KSP_REORDER": "0"}, {"KSP_NO_SCHED": "1"}, {"KSP_COLLECT": "1"}, {"KSP_COLLECT": "0"},
-         {"KSP_JOIN": "window"}, {"KSP_TAG32": "1"}, {"KSP_HASH_GROUP": "0"}]
+         {"KSP_JOIN": "window"}, {"KSP_TAG32": "1"}, {"KSP_HASH_GROUP": "0"}, {"KSP_KEY_GROUPS": "0"},
+         {"KSP_KEY_GROUPS": "0", "KSP_REORDER": "0"}]
 
 
 def _random_sketches(rng):
@@ -36,7 +37,7 @@ def test_random_sketches_all_modes(oracle_lib, seed, monkeypatch):
         sk = _random_sketches(rng)
         ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
         for env in MODES:
-            for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_JOIN", "KSP_TAG32", "KSP_HASH_GROUP"):
+            for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_JOIN", "KSP_TAG32", "KSP_HASH_GROUP", "KSP_KEY_GROUPS"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
@@ -70,8 +71,8 @@ def test_random_weighted_and_postings(oracle_lib, seed, monkeypatch):
             for x in range(g.size):
                 for y in range(x + 1, g.size):
                     want[(int(g[x]), int(g[y]))] = want.get((int(g[x]), int(g[y])), 0) + w
-        for env in ({}, {"KSP_REORDER": "0"}, {"KSP_NO_SCHED": "1"}):
-            for k in ("KSP_REORDER", "KSP_NO_SCHED"):
+        for env in ({}, {"KSP_REORDER": "0"}, {"KSP_NO_SCHED": "1"}, {"KSP_KEY_GROUPS": "0"}):
+            for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_KEY_GROUPS"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
