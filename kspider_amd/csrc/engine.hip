@@ -111,7 +111,7 @@ struct ksp_engine {
     u32 hb_slots = 0;             // workgroups of k_bucket_group the device holds at once
     bool key_groups_off = false;  // a key has too many holders for the key-by-key list build: sort the entries by block
     bool have_rank_pairs = false; // gp holds (block, rank) of every list word in rank order (key-by-key build)
-    ksp::Buf gp;
+    ksp::Buf gp, gm;              // group records of the key-by-key build; parked masks
     bool reorder = true;          // order the sources by shared-key label before cutting blocks (KSP_REORDER=0: off)
     bool need32 = false;          // some tile pairs two blocks that both hold a source with >= 2^16 k-mers
     int key_bits = 64;
@@ -420,13 +420,16 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         const u32* firstp = phase == 3 ? e->post_off : (const u32*)e->FK.p;   // where each key's entries start (sentinel at U)
         u64* gsum = (u64*)KA;                 // per key: groups | masks << 32   (KA: the sorted keys are dead)
         u64* goff = gsum + (U + 2);
+        u32* tmp_blk = (u32*)e->KB.p;         // records parked at entry positions (KB: free since the grouping by key)
+        u32* tmp_info = tmp_blk + (m + 2);
+        if ((rc = e->gm.ensure(((size_t)m / 4 + 4) * 16))) return rc;
+        u32* wkey = W ? (u32*)VB : nullptr;   // (VB: the partitioned tags are dead)
         u32* d_kovf = (u32*)(scal + 11);
         const u32 chunks = (u32)((m + KG_CHUNK - 1) / KG_CHUNK);
         KSP_HIP(hipMemsetAsync(d_kovf, 0, 8, st));
         KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input — are visited by no chunk)
-        hipLaunchKernelGGL((k_key_groups<V, 0, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, rank1, firstp, newidx, (u32)m, U,
-                           gsum, (const u64*)nullptr, (u32*)nullptr, (u64*)nullptr, (u32*)nullptr, (uint4*)nullptr,
-                           (u32*)nullptr, d_kovf);
+        hipLaunchKernelGGL((k_key_groups<V, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, rank1, firstp, newidx, (u32)m, U,
+                           gsum, tmp_blk, tmp_info, e->gm.as<uint4>(), wkey, d_kovf);
         tb = 0;
         KSP_HIP(rocprim::exclusive_scan(nullptr, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
         if ((rc = e->tmp.ensure(tb))) return rc;
@@ -440,13 +443,12 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             e->key_groups_off = true;   // a key with thousands of holders: this engine sorts by block from now on
         } else {
             const u64 K = std::max<u64>(1, e->h_scal[1]);
-            if ((rc = e->gp.ensure((K + 4) * 12))) return rc;
-            u32 *rec_blk = e->gp.as<u32>(), *rec_rank = rec_blk + (K + 4), *sblk = rec_rank + (K + 4);
-            u64* rec_val = (u64*)e->KB.p;     // (KB: free since the grouping by key)
-            u64* sval = (u64*)KA;             // (the per-key counts and offsets are dead once the records are written)
-            u32* wkey = W ? (u32*)VB : nullptr;   // (VB: the partitioned tags are dead)
-            hipLaunchKernelGGL((k_key_groups<V, 1, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, rank1, firstp, newidx, (u32)m,
-                               U, (u64*)nullptr, goff, rec_blk, rec_val, rec_rank, e->mm.as<uint4>(), wkey, d_kovf);
+            if ((rc = e->gp.ensure((K + 4) * 20))) return rc;
+            u64* rec_val = e->gp.as<u64>();
+            u32 *rec_blk = (u32*)(rec_val + (K + 4)), *rec_rank = rec_blk + (K + 4), *sblk = rec_rank + (K + 4);
+            u64* sval = (u64*)KA;             // (the per-key counts and offsets are dead once the records are packed)
+            hipLaunchKernelGGL(k_move_groups, dim3(grid_for(U, bs)), dim3(bs), 0, st, gsum, goff, firstp, tmp_blk, tmp_info,
+                               e->gm.as<uint4>(), rec_blk, rec_val, rec_rank, e->mm.as<uint4>(), U);
             tb = 0;
             KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
             if ((rc = e->tmp.ensure(tb))) return rc;
@@ -543,7 +545,8 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
         if ((rc = e->KB.ensure((K + 4) * 8))) return rc;
     }
     u32 *pr = ranked ? nullptr : (u32*)e->KA.p, *pb = ranked ? nullptr : pr + (K + 4);
-    u32 *pr2 = ranked ? e->gp.as<u32>() + (K + 4) : (u32*)e->KB.p, *pb2 = ranked ? e->gp.as<u32>() : pr2 + (K + 4);
+    // (gp: K + 4 record values, then the blocks, then the ranks — see build_impl)
+    u32 *pr2 = ranked ? e->gp.as<u32>() + 3 * (K + 4) : (u32*)e->KB.p, *pb2 = ranked ? e->gp.as<u32>() + 2 * (K + 4) : pr2 + (K + 4);
     unsigned char* flags = (unsigned char*)e->tbits.p + bit_words * 4;
     KSP_HIP(hipMemsetAsync(e->tbits.p, 0, bit_words * 4 + T + 64, st));
     KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
@@ -616,7 +619,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
-                        &e->d_wg, &e->gp};
+                        &e->d_wg, &e->gp, &e->gm};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);

@@ -540,22 +540,22 @@ struct PruneScatterIt {
 // After the grouping by key the entries of a key are contiguous (first[]), and after the source
 // reordering nearly all of a key's holders sit in one block: the (block, key) groups — the words of
 // the block lists — can be read off key by key, and only the *groups* (an order of magnitude fewer than
-// the entries) have to be brought into block order.  Two passes over the entries (count, then emit):
-// a workgroup stages a chunk of entries in LDS as new source indices, one thread per key walks its
-// holders block by block (ascending), building the 128-bit membership mask of each group.
-// Pass 0 leaves per key (groups | groups with more than INLINE_MAX members << 32); pass 1 writes, at the
-// scanned offsets, the group records in rank order: block, rank << 32 | posting word, and the masks.
+// the entries) have to be brought into block order.  A workgroup stages a chunk of entries in LDS as
+// new source indices; one thread per key walks its holders block by block (ascending), building the
+// 128-bit membership mask of each group.  A key with c holders has at most c groups and c/5 groups
+// with more than INLINE_MAX members, so its records are parked at its own entry positions (block and
+// posting word at first[r] + j, masks at first[r]/4 + j) — no offsets needed yet.  gsum[r] = groups |
+// masks << 32; after the scan k_move_groups packs the records in rank order.
 // Keys with more than KG_MAXC holders do not fit the staging: they raise *ovf and the build takes the
 // sort-by-block path instead.
 constexpr u32 KG_CHUNK = 4096, KG_MAXC = 2048, KG_THREADS = 256;
 
-template <class V, int PASS, bool W>
+template <class V, bool W>
 __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__ vals, const u32* __restrict__ rank,
                                                            const u32* __restrict__ first, const u32* __restrict__ newidx,
                                                            u32 m, u32 n_keys, u64* __restrict__ gsum,
-                                                           const u64* __restrict__ goff, u32* __restrict__ rec_blk,
-                                                           u64* __restrict__ rec_val, u32* __restrict__ rec_rank,
-                                                           uint4* __restrict__ bigmask, u32* __restrict__ wkey,
+                                                           u32* __restrict__ tmp_blk, u32* __restrict__ tmp_info,
+                                                           uint4* __restrict__ tmp_mask, u32* __restrict__ wkey,
                                                            u32* __restrict__ ovf) {
     __shared__ u32 s_idx[KG_CHUNK + KG_MAXC];
     const u32 E0 = blockIdx.x * KG_CHUNK, E1 = min(m, E0 + KG_CHUNK);
@@ -572,17 +572,13 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
         const u32 fa = first[r], c = first[r + 1] - fa, f0 = fa - E0;
         if (c > KG_MAXC) {
             *ovf = 1;
-            if (PASS == 0) gsum[r] = 0;
+            gsum[r] = 0;
             continue;
         }
+        if (W && c) wkey[r] = weight_of(vals[fa]);
         u32 cur = ~0u;
         for (u32 i = 0; i < c; ++i) cur = min(cur, s_idx[f0 + i] / TB);
         u32 groups = 0, bigs = 0;
-        u64 base = 0;
-        if (PASS == 1) {
-            base = goff[r];
-            if (W) wkey[r] = weight_of(vals[fa]);
-        }
         while (cur != ~0u) {
             u32 nxt = ~0u;
             unsigned long long lo = 0, hi = 0;
@@ -594,32 +590,54 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
                 } else if (b > cur && b < nxt) nxt = b;
             }
             const u32 cnt = __popcll(lo) + __popcll(hi);
-            if (PASS == 1) {
-                u32 inf;
-                if (cnt <= INLINE_MAX) {
-                    inf = (cnt - 1) << 29;
-                    unsigned long long a = lo, bq = hi;
-                    for (u32 j = 0; j < cnt; ++j) {   // local ids, ascending, 7 bits each
-                        u32 id;
-                        if (a) { id = __ffsll((long long)a) - 1; a &= a - 1; }
-                        else { id = 64 + __ffsll((long long)bq) - 1; bq &= bq - 1; }
-                        inf |= id << (7 * j);
-                    }
-                } else {
-                    const u32 o = (u32)(base >> 32) + bigs;
-                    bigmask[o] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
-                    inf = BIG | o;
+            u32 inf;
+            if (cnt <= INLINE_MAX) {
+                inf = (cnt - 1) << 29;
+                unsigned long long a = lo, bq = hi;
+                for (u32 j = 0; j < cnt; ++j) {   // local ids, ascending, 7 bits each
+                    u32 id;
+                    if (a) { id = __ffsll((long long)a) - 1; a &= a - 1; }
+                    else { id = 64 + __ffsll((long long)bq) - 1; bq &= bq - 1; }
+                    inf |= id << (7 * j);
                 }
-                const u32 g = (u32)base + groups;
-                rec_blk[g] = cur;
-                rec_val[g] = ((u64)r << 32) | inf;
-                rec_rank[g] = r;
+            } else {
+                const u32 slot = fa / 4 + bigs;
+                tmp_mask[slot] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+                inf = BIG | slot;
+                ++bigs;
             }
+            tmp_blk[fa + groups] = cur;
+            tmp_info[fa + groups] = inf;
             ++groups;
-            bigs += cnt > INLINE_MAX;
             cur = nxt;
         }
-        if (PASS == 0) gsum[r] = (u64)groups | ((u64)bigs << 32);
+        gsum[r] = (u64)groups | ((u64)bigs << 32);
+    }
+}
+// the parked records to their places in rank order (goff = exclusive scan of gsum): block, rank << 32 |
+// posting word, rank; masks to their final index
+__global__ void k_move_groups(const u64* __restrict__ gsum, const u64* __restrict__ goff, const u32* __restrict__ first,
+                              const u32* __restrict__ tmp_blk, const u32* __restrict__ tmp_info,
+                              const uint4* __restrict__ tmp_mask, u32* __restrict__ rec_blk, u64* __restrict__ rec_val,
+                              u32* __restrict__ rec_rank, uint4* __restrict__ bigmask, u32 n_keys) {
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_keys) return;
+    const u32 k = (u32)gsum[r];
+    if (!k) return;
+    const u64 base = goff[r];
+    const u32 fa = first[r];
+    u32 o = (u32)(base >> 32);
+    for (u32 j = 0; j < k; ++j) {
+        u32 inf = tmp_info[fa + j];
+        if (inf >= BIG) {
+            bigmask[o] = tmp_mask[inf & ~BIG];
+            inf = BIG | o;
+            ++o;
+        }
+        const u32 g = (u32)base + j;
+        rec_blk[g] = tmp_blk[fa + j];
+        rec_val[g] = ((u64)r << 32) | inf;
+        rec_rank[g] = r;
     }
 }
 // totals of the group scan: scal[1] = list words (groups), scal[7] = masks
