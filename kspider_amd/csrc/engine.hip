@@ -422,14 +422,18 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         u64* goff = gsum + (U + 2);
         u32* tmp_blk = (u32*)e->KB.p;         // records parked at entry positions (KB: free since the grouping by key)
         u32* tmp_info = tmp_blk + (m + 2);
-        if ((rc = e->gm.ensure(((size_t)m / 4 + 4) * 16))) return rc;
+        // gm: per key the mask, block and posting word of its first group, then the parked masks of further groups
+        if ((rc = e->gm.ensure(((size_t)U + 4) * 24 + ((size_t)m / 4 + 4) * 16))) return rc;
+        uint4* mask0 = e->gm.as<uint4>();
+        uint4* tmp_mask = mask0 + (U + 4);
+        u32 *blk0 = (u32*)(tmp_mask + (m / 4 + 4)), *info0 = blk0 + (U + 4);
         u32* wkey = W ? (u32*)VB : nullptr;   // (VB: the partitioned tags are dead)
         u32* d_kovf = (u32*)(scal + 11);
         const u32 chunks = (u32)((m + KG_CHUNK - 1) / KG_CHUNK);
         KSP_HIP(hipMemsetAsync(d_kovf, 0, 8, st));
         KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input — are visited by no chunk)
         hipLaunchKernelGGL((k_key_groups<V, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, rank1, firstp, newidx, (u32)m, U,
-                           gsum, tmp_blk, tmp_info, e->gm.as<uint4>(), wkey, d_kovf);
+                           gsum, blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf);
         tb = 0;
         KSP_HIP(rocprim::exclusive_scan(nullptr, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
         if ((rc = e->tmp.ensure(tb))) return rc;
@@ -447,8 +451,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             u64* rec_val = e->gp.as<u64>();
             u32 *rec_blk = (u32*)(rec_val + (K + 4)), *rec_rank = rec_blk + (K + 4), *sblk = rec_rank + (K + 4);
             u64* sval = (u64*)KA;             // (the per-key counts and offsets are dead once the records are packed)
-            hipLaunchKernelGGL(k_move_groups, dim3(grid_for(U, bs)), dim3(bs), 0, st, gsum, goff, firstp, tmp_blk, tmp_info,
-                               e->gm.as<uint4>(), rec_blk, rec_val, rec_rank, e->mm.as<uint4>(), U);
+            hipLaunchKernelGGL(k_move_groups, dim3(grid_for(U, bs)), dim3(bs), 0, st, gsum, goff, firstp, blk0, info0, mask0,
+                               tmp_blk, tmp_info, tmp_mask, rec_blk, rec_val, rec_rank, e->mm.as<uint4>(), U);
             tb = 0;
             KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
             if ((rc = e->tmp.ensure(tb))) return rc;

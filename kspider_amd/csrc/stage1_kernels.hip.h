@@ -543,9 +543,10 @@ struct PruneScatterIt {
 // the entries) have to be brought into block order.  A workgroup stages a chunk of entries in LDS as
 // new source indices; one thread per key walks its holders block by block (ascending), building the
 // 128-bit membership mask of each group.  A key with c holders has at most c groups and c/5 groups
-// with more than INLINE_MAX members, so its records are parked at its own entry positions (block and
-// posting word at first[r] + j, masks at first[r]/4 + j) — no offsets needed yet.  gsum[r] = groups |
-// masks << 32; after the scan k_move_groups packs the records in rank order.
+// with more than INLINE_MAX members, so its records can be parked without knowing any offsets yet: the
+// first group of key r (for most keys the only one) in per-key arrays at index r, further groups at the
+// key's own entry positions (block and posting word at first[r] + j, masks at first[r]/4 + j).
+// gsum[r] = groups | masks << 32; after the scan k_move_groups packs the records in rank order.
 // Keys with more than KG_MAXC holders do not fit the staging: they raise *ovf and the build takes the
 // sort-by-block path instead.
 constexpr u32 KG_CHUNK = 4096, KG_MAXC = 2048, KG_THREADS = 256;
@@ -554,9 +555,10 @@ template <class V, bool W>
 __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__ vals, const u32* __restrict__ rank,
                                                            const u32* __restrict__ first, const u32* __restrict__ newidx,
                                                            u32 m, u32 n_keys, u64* __restrict__ gsum,
-                                                           u32* __restrict__ tmp_blk, u32* __restrict__ tmp_info,
-                                                           uint4* __restrict__ tmp_mask, u32* __restrict__ wkey,
-                                                           u32* __restrict__ ovf) {
+                                                           u32* __restrict__ blk0, u32* __restrict__ info0,
+                                                           uint4* __restrict__ mask0, u32* __restrict__ tmp_blk,
+                                                           u32* __restrict__ tmp_info, uint4* __restrict__ tmp_mask,
+                                                           u32* __restrict__ wkey, u32* __restrict__ ovf) {
     __shared__ u32 s_idx[KG_CHUNK + KG_MAXC];
     const u32 E0 = blockIdx.x * KG_CHUNK, E1 = min(m, E0 + KG_CHUNK);
     // the keys that start inside [E0, E1)
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
         if (W && c) wkey[r] = weight_of(vals[fa]);
         u32 cur = ~0u;
         for (u32 i = 0; i < c; ++i) cur = min(cur, s_idx[f0 + i] / TB);
-        u32 groups = 0, bigs = 0;
+        u32 groups = 0, bigs = 0, parked = 0;
         while (cur != ~0u) {
             u32 nxt = ~0u;
             unsigned long long lo = 0, hi = 0;
@@ -601,13 +603,13 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
                     inf |= id << (7 * j);
                 }
             } else {
-                const u32 slot = fa / 4 + bigs;
-                tmp_mask[slot] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
-                inf = BIG | slot;
+                const uint4 mask = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+                if (groups == 0) { mask0[r] = mask; inf = BIG; }
+                else { const u32 slot = fa / 4 + parked; tmp_mask[slot] = mask; inf = BIG | slot; ++parked; }
                 ++bigs;
             }
-            tmp_blk[fa + groups] = cur;
-            tmp_info[fa + groups] = inf;
+            if (groups == 0) { blk0[r] = cur; info0[r] = inf; }
+            else { tmp_blk[fa + groups] = cur; tmp_info[fa + groups] = inf; }
             ++groups;
             cur = nxt;
         }
@@ -617,6 +619,7 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
 // the parked records to their places in rank order (goff = exclusive scan of gsum): block, rank << 32 |
 // posting word, rank; masks to their final index
 __global__ void k_move_groups(const u64* __restrict__ gsum, const u64* __restrict__ goff, const u32* __restrict__ first,
+                              const u32* __restrict__ blk0, const u32* __restrict__ info0, const uint4* __restrict__ mask0,
                               const u32* __restrict__ tmp_blk, const u32* __restrict__ tmp_info,
                               const uint4* __restrict__ tmp_mask, u32* __restrict__ rec_blk, u64* __restrict__ rec_val,
                               u32* __restrict__ rec_rank, uint4* __restrict__ bigmask, u32 n_keys) {
@@ -625,16 +628,21 @@ __global__ void k_move_groups(const u64* __restrict__ gsum, const u64* __restric
     const u32 k = (u32)gsum[r];
     if (!k) return;
     const u64 base = goff[r];
-    const u32 fa = first[r];
     u32 o = (u32)(base >> 32);
-    for (u32 j = 0; j < k; ++j) {
+    u32 g = (u32)base;
+    {   // the key's first group: per-key arrays
+        u32 inf = info0[r];
+        if (inf >= BIG) { bigmask[o] = mask0[r]; inf = BIG | o; ++o; }
+        rec_blk[g] = blk0[r];
+        rec_val[g] = ((u64)r << 32) | inf;
+        rec_rank[g] = r;
+    }
+    if (k == 1) return;
+    const u32 fa = first[r];
+    for (u32 j = 1; j < k; ++j) {
         u32 inf = tmp_info[fa + j];
-        if (inf >= BIG) {
-            bigmask[o] = tmp_mask[inf & ~BIG];
-            inf = BIG | o;
-            ++o;
-        }
-        const u32 g = (u32)base + j;
+        if (inf >= BIG) { bigmask[o] = tmp_mask[inf & ~BIG]; inf = BIG | o; ++o; }
+        ++g;
         rec_blk[g] = tmp_blk[fa + j];
         rec_val[g] = ((u64)r << 32) | inf;
         rec_rank[g] = r;
