@@ -111,6 +111,7 @@ struct ksp_engine {
     u32 hb_slots = 0;             // workgroups of k_bucket_group the device holds at once
     bool key_groups_off = false;  // a key has too many holders for the key-by-key list build: sort the entries by block
     bool have_rank_pairs = false; // gp holds (block, rank) of every list word in rank order (key-by-key build)
+    bool have_dwork = false;      // ... and dwork the diagonal work / holder sums (k_move_groups)
     ksp::Buf gp, gm;              // group records of the key-by-key build; parked masks
     bool reorder = true;          // order the sources by shared-key label before cutting blocks (KSP_REORDER=0: off)
     bool need32 = false;          // some tile pairs two blocks that both hold a source with >= 2^16 k-mers
@@ -414,6 +415,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     }
     if (m == 0) return KSP_OK;
     e->have_rank_pairs = false;
+    e->have_dwork = false;
     // ---- the block lists, key by key (see k_key_groups) ------------------------------------------------
     if (!e->key_groups_off && m < (1ull << 32) - KG_CHUNK) {
         const u32 U = (u32)e->h_scal[2];
@@ -451,8 +453,17 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             u64* rec_val = e->gp.as<u64>();
             u32 *rec_blk = (u32*)(rec_val + (K + 4)), *rec_rank = rec_blk + (K + 4), *sblk = rec_rank + (K + 4);
             u64* sval = (u64*)KA;             // (the per-key counts and offsets are dead once the records are packed)
-            hipLaunchKernelGGL(k_move_groups, dim3(grid_for(U, bs)), dim3(bs), 0, st, gsum, goff, firstp, blk0, info0, mask0,
-                               tmp_blk, tmp_info, tmp_mask, rec_blk, rec_val, rec_rank, e->mm.as<uint4>(), U);
+            // (the diagonal work and holder sums of the join's schedule come with the move when the blocks fit its LDS table)
+            unsigned long long* work = nullptr;
+            if (nb <= KG_WORK && phase != 2) {
+                if ((rc = e->dwork.ensure(((size_t)nb + 2) * 8))) return rc;
+                KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
+                work = e->dwork.as<unsigned long long>();
+            }
+            hipLaunchKernelGGL(k_move_groups, dim3(std::min<u32>(grid_for(U, bs), 512u)), dim3(bs), 0, st, gsum, goff, firstp,
+                               blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, rec_blk, rec_val, rec_rank, e->mm.as<uint4>(),
+                               U, work, nb);
+            e->have_dwork = work != nullptr;
             tb = 0;
             KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
             if ((rc = e->tmp.ensure(tb))) return rc;
@@ -553,11 +564,13 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     u32 *pr2 = ranked ? e->gp.as<u32>() + 3 * (K + 4) : (u32*)e->KB.p, *pb2 = ranked ? e->gp.as<u32>() + 2 * (K + 4) : pr2 + (K + 4);
     unsigned char* flags = (unsigned char*)e->tbits.p + bit_words * 4;
     KSP_HIP(hipMemsetAsync(e->tbits.p, 0, bit_words * 4 + T + 64, st));
-    KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
-    const u32 shares = (u32)std::min<u64>(64, std::max<u64>(1, 2048 / nb));
-    hipLaunchKernelGGL(k_list_pairs, dim3(nb, shares), dim3(256), 0, st, e->bkeys.as<u32>(), e->info.as<u32>(),
-                       e->mm.as<uint4>(), e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), pr, pb,
-                       e->dwork.as<unsigned long long>());
+    if (!(ranked && e->have_dwork)) {
+        KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
+        const u32 shares = (u32)std::min<u64>(64, std::max<u64>(1, 2048 / nb));
+        hipLaunchKernelGGL(k_list_pairs, dim3(nb, shares), dim3(256), 0, st, e->bkeys.as<u32>(), e->info.as<u32>(),
+                           e->mm.as<uint4>(), e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), pr, pb,
+                           e->dwork.as<unsigned long long>());
+    }
     if (!ranked) {
         int rbits = 1;
         while (rbits < 32 && (U >> rbits)) ++rbits;
@@ -1080,6 +1093,7 @@ int ksp_engine_assemble(ksp_engine* e, uint32_t nparts, const uint64_t* h_sizes 
     e->h_scal_words = ktot;
     e->h_scal_keys = utot;
     e->have_rank_pairs = false;   // (the assembled lists: pairs from the lists themselves)
+    e->have_dwork = false;
     if ((rc = launch_sched_kernels(e, st))) return rc;
     KSP_HIP(hipEventRecord(e->ev[1], st));
     KSP_HIP(hipStreamSynchronize(st));

@@ -578,18 +578,20 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
             continue;
         }
         if (W && c) wkey[r] = weight_of(vals[fa]);
-        u32 cur = ~0u;
-        for (u32 i = 0; i < c; ++i) cur = min(cur, s_idx[f0 + i] / TB);
+        // the block of the first holder first (for most keys the only one: a single walk), then the others ascending
+        const u32 b0 = c ? s_idx[f0] / TB : ~0u;
+        u32 cur = b0;
         u32 groups = 0, bigs = 0, parked = 0;
         while (cur != ~0u) {
             u32 nxt = ~0u;
             unsigned long long lo = 0, hi = 0;
+            const u32 floor_b = groups == 0 ? 0u : cur + 1;   // (first walk: the smallest other block; later: the next one up)
             for (u32 i = 0; i < c; ++i) {
                 const u32 t = s_idx[f0 + i], b = t / TB;
                 if (b == cur) {
                     const u32 l = t % TB;
                     if (l < 64) lo |= 1ull << l; else hi |= 1ull << (l - 64);
-                } else if (b > cur && b < nxt) nxt = b;
+                } else if (b >= floor_b && b != b0 && b < nxt) nxt = b;
             }
             const u32 cnt = __popcll(lo) + __popcll(hi);
             u32 inf;
@@ -617,35 +619,60 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
     }
 }
 // the parked records to their places in rank order (goff = exclusive scan of gsum): block, rank << 32 |
-// posting word, rank; masks to their final index
-__global__ void k_move_groups(const u64* __restrict__ gsum, const u64* __restrict__ goff, const u32* __restrict__ first,
-                              const u32* __restrict__ blk0, const u32* __restrict__ info0, const uint4* __restrict__ mask0,
-                              const u32* __restrict__ tmp_blk, const u32* __restrict__ tmp_info,
-                              const uint4* __restrict__ tmp_mask, u32* __restrict__ rec_blk, u64* __restrict__ rec_val,
-                              u32* __restrict__ rec_rank, uint4* __restrict__ bigmask, u32 n_keys) {
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_keys) return;
-    const u32 k = (u32)gsum[r];
-    if (!k) return;
-    const u64 base = goff[r];
-    u32 o = (u32)(base >> 32);
-    u32 g = (u32)base;
-    {   // the key's first group: per-key arrays
-        u32 inf = info0[r];
-        if (inf >= BIG) { bigmask[o] = mask0[r]; inf = BIG | o; ++o; }
-        rec_blk[g] = blk0[r];
-        rec_val[g] = ((u64)r << 32) | inf;
-        rec_rank[g] = r;
+// posting word, rank; masks to their final index.  With `work` set (at most KG_WORK blocks) the kernel also
+// sums what the join's schedule needs — per block the pair updates of its diagonal tile, C(holders, 2) per
+// group, and in slot nb the holders of all groups — in LDS per workgroup (a few hundred persistent ones).
+constexpr u32 KG_WORK = 2048;
+__global__ __launch_bounds__(256) void k_move_groups(const u64* __restrict__ gsum, const u64* __restrict__ goff,
+                                                     const u32* __restrict__ first, const u32* __restrict__ blk0,
+                                                     const u32* __restrict__ info0, const uint4* __restrict__ mask0,
+                                                     const u32* __restrict__ tmp_blk, const u32* __restrict__ tmp_info,
+                                                     const uint4* __restrict__ tmp_mask, u32* __restrict__ rec_blk,
+                                                     u64* __restrict__ rec_val, u32* __restrict__ rec_rank,
+                                                     uint4* __restrict__ bigmask, u32 n_keys,
+                                                     unsigned long long* __restrict__ work, u32 nb) {
+    __shared__ unsigned long long s_work[KG_WORK + 1];
+    if (work) {
+        for (u32 i = threadIdx.x; i <= nb; i += blockDim.x) s_work[i] = 0;
+        __syncthreads();
     }
-    if (k == 1) return;
-    const u32 fa = first[r];
-    for (u32 j = 1; j < k; ++j) {
-        u32 inf = tmp_info[fa + j];
-        if (inf >= BIG) { bigmask[o] = tmp_mask[inf & ~BIG]; inf = BIG | o; ++o; }
-        ++g;
-        rec_blk[g] = tmp_blk[fa + j];
-        rec_val[g] = ((u64)r << 32) | inf;
-        rec_rank[g] = r;
+    unsigned long long holders = 0;
+    for (u32 r = blockIdx.x * blockDim.x + threadIdx.x; r < n_keys; r += gridDim.x * blockDim.x) {
+        const u32 k = (u32)gsum[r];
+        if (!k) continue;
+        const u64 base = goff[r];
+        u32 o = (u32)(base >> 32);
+        u32 g = (u32)base;
+        u32 fa = 0;
+        for (u32 j = 0; j < k; ++j, ++g) {
+            u32 inf, blk, cnt;
+            if (j == 0) { inf = info0[r]; blk = blk0[r]; }   // the key's first group: per-key arrays
+            else {
+                if (j == 1) fa = first[r];
+                inf = tmp_info[fa + j]; blk = tmp_blk[fa + j];
+            }
+            if (inf >= BIG) {
+                const uint4 mk = j == 0 ? mask0[r] : tmp_mask[inf & ~BIG];
+                cnt = __popc(mk.x) + __popc(mk.y) + __popc(mk.z) + __popc(mk.w);
+                bigmask[o] = mk;
+                inf = BIG | o;
+                ++o;
+            } else cnt = (inf >> 29) + 1;
+            rec_blk[g] = blk;
+            rec_val[g] = ((u64)r << 32) | inf;
+            rec_rank[g] = r;
+            if (work) {
+                holders += cnt;
+                if (cnt > 1) atomicAdd(&s_work[blk], (unsigned long long)cnt * (cnt - 1) / 2);
+            }
+        }
+    }
+    if (work) {
+        for (int o = 32; o > 0; o >>= 1) holders += __shfl_down(holders, o);
+        if ((threadIdx.x & 63) == 0 && holders) atomicAdd(&s_work[nb], holders);
+        __syncthreads();
+        for (u32 i = threadIdx.x; i <= nb; i += blockDim.x)
+            if (s_work[i]) atomicAdd(&work[i], s_work[i]);
     }
 }
 // totals of the group scan: scal[1] = list words (groups), scal[7] = masks
