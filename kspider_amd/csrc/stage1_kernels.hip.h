@@ -559,7 +559,7 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
                                                            uint4* __restrict__ mask0, u32* __restrict__ tmp_blk,
                                                            u32* __restrict__ tmp_info, uint4* __restrict__ tmp_mask,
                                                            u32* __restrict__ wkey, u32* __restrict__ ovf) {
-    __shared__ u32 s_idx[KG_CHUNK + KG_MAXC];
+    __shared__ u32 s_idx[KG_CHUNK + KG_MAXC + 4];
     const u32 E0 = blockIdx.x * KG_CHUNK, E1 = min(m, E0 + KG_CHUNK);
     // the keys that start inside [E0, E1)
     u32 r_lo = rank[E0];
@@ -586,12 +586,19 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
             u32 nxt = ~0u;
             unsigned long long lo = 0, hi = 0;
             const u32 floor_b = groups == 0 ? 0u : cur + 1;   // (first walk: the smallest other block; later: the next one up)
-            for (u32 i = 0; i < c; ++i) {
-                const u32 t = s_idx[f0 + i], b = t / TB;
-                if (b == cur) {
-                    const u32 l = t % TB;
-                    if (l < 64) lo |= 1ull << l; else hi |= 1ull << (l - 64);
-                } else if (b >= floor_b && b != b0 && b < nxt) nxt = b;
+            for (u32 i = 0; i < c; i += 4) {   // four holders per step: the LDS reads of a step are independent
+                u32 t4[4];
+#pragma unroll
+                for (u32 q = 0; q < 4; ++q) t4[q] = s_idx[f0 + i + q];   // (the staging area has 4 words of slack)
+#pragma unroll
+                for (u32 q = 0; q < 4; ++q) {
+                    if (i + q >= c) break;
+                    const u32 t = t4[q], b = t / TB;
+                    if (b == cur) {
+                        const u32 l = t % TB;
+                        if (l < 64) lo |= 1ull << l; else hi |= 1ull << (l - 64);
+                    } else if (b >= floor_b && b != b0 && b < nxt) nxt = b;
+                }
             }
             const u32 cnt = __popcll(lo) + __popcll(hi);
             u32 inf;
