@@ -253,7 +253,7 @@ def main():
                                  "8(n_a+n_b)+4; the kernel streams block-merged rank lists instead, "
                                  "see stream_model"},
             "stage1_sort": (lambda ms, n_e, bits, tb=(2 if n <= 65536 and not os.environ.get("KSP_TAG32") else 4): {
-                "kernel": "rocprim radix_sort_onesweep (global sort of stage 1: the largest kernel group of the step)",
+                "kernel": "rocprim radix_sort_onesweep (stage 1 partitions the entries by their top key bits before the LDS hash grouping: the largest kernel group of the step)",
                 "entries": n_e, "key_bits": bits, "passes": (bits + 7) // 8, "ms": ms,
                 "bytes": n_e * (8 + tb) * 2 * ((bits + 7) // 8),
                 "GBps": (n_e * (8 + tb) * 2 * ((bits + 7) // 8)) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,

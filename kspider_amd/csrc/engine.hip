@@ -148,11 +148,25 @@ namespace ksp {
 static inline unsigned grid_for(u64 n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
 // The label pass looks at one key in (result + 1): ~64 sampled shared keys per source say as much about a
-// source's relatives as all of them (sources with thousands of shared keys are the common case).
-static u32 label_sampling(u64 kept_entries, u32 n_sources) {
-    const u64 per_source = kept_entries / std::max<u32>(1, n_sources);
+// source's relatives as all of them.  "Per source" is the small end of the size distribution (the 10th
+// percentile of up to 1024 evenly spaced sources), so that small sketches among large ones still get their
+// labels (lognormal sizes: C4).
+static u32 label_sampling(const ksp_engine* e, u64 kept_entries) {
+    const u32 N = std::max<u32>(1, e->n_sources);
+    u64 small = kept_entries / N / 4;
+    if (e->h_off.size() == (size_t)N + 1 && e->n_entries) {
+        std::vector<u64> sz;
+        const u32 take = std::min<u32>(N, 1024);
+        sz.reserve(take);
+        for (u32 i = 0; i < take; ++i) {
+            const size_t s = (size_t)((u64)i * N / take);
+            sz.push_back(e->h_off[s + 1] - e->h_off[s]);
+        }
+        std::nth_element(sz.begin(), sz.begin() + take / 10, sz.end());
+        small = (u64)((double)sz[take / 10] * (double)kept_entries / (double)e->n_entries);
+    }
     u32 every = 1;
-    while (every < 64 && per_source / (2 * every) >= 64) every *= 2;
+    while (every < 64 && small / (2 * every) >= 64) every *= 2;
     return every - 1;
 }
 
@@ -202,7 +216,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if (const char* lm = std::getenv("KSP_DEBUG_LABEL_MAX")) label_max = (u32)std::max(1, std::atoi(lm));
     // the label pass over the kept keys (first[] = where each key's entries start); KB is free whenever it runs
     auto run_label = [&](const u32* firstp, const u32 n_keys, const u64 kept) {
-        const u32 skip = label_sampling(kept, N);
+        const u32 skip = label_sampling(e, kept);
         const int ls = e->KB.bytes >= (size_t)N * 128 ? 5 : 0;
         u32* lab = ls ? (u32*)e->KB.p : label;
         if (ls) hipLaunchKernelGGL(k_label_spread, dim3(grid_for(N, bs)), dim3(bs), 0, st, lab, ls, N);
@@ -435,7 +449,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         KSP_HIP(hipMemsetAsync(d_kovf, 0, 8, st));
         KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input — are visited by no chunk)
         hipLaunchKernelGGL((k_key_groups<V, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, rank1, firstp, newidx, (u32)m, U,
-                           gsum, blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf);
+                           gsum, blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf,
+                           std::getenv("KSP_DEBUG_COOP") ? std::max<u32>(KG_COOP, (u32)std::atoi(std::getenv("KSP_DEBUG_COOP"))) : KG_COOP);   // (timing experiments: raise the wave-per-key threshold)
         tb = 0;
         KSP_HIP(rocprim::exclusive_scan(nullptr, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
         if ((rc = e->tmp.ensure(tb))) return rc;

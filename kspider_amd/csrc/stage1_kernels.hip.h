@@ -549,7 +549,7 @@ struct PruneScatterIt {
 // gsum[r] = groups | masks << 32; after the scan k_move_groups packs the records in rank order.
 // Keys with more than KG_MAXC holders do not fit the staging: they raise *ovf and the build takes the
 // sort-by-block path instead.
-constexpr u32 KG_CHUNK = 4096, KG_MAXC = 2048, KG_THREADS = 256;
+constexpr u32 KG_CHUNK = 4096, KG_MAXC = 2048, KG_THREADS = 256, KG_COOP = 64;
 
 template <class V, bool W>
 __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__ vals, const u32* __restrict__ rank,
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
                                                            u32* __restrict__ blk0, u32* __restrict__ info0,
                                                            uint4* __restrict__ mask0, u32* __restrict__ tmp_blk,
                                                            u32* __restrict__ tmp_info, uint4* __restrict__ tmp_mask,
-                                                           u32* __restrict__ wkey, u32* __restrict__ ovf) {
+                                                           u32* __restrict__ wkey, u32* __restrict__ ovf, const u32 coop) {
     __shared__ u32 s_idx[KG_CHUNK + KG_MAXC + 4];
     const u32 E0 = blockIdx.x * KG_CHUNK, E1 = min(m, E0 + KG_CHUNK);
     // the keys that start inside [E0, E1)
@@ -570,11 +570,45 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
     const u32 Eend = min(first[r_hi], E0 + KG_CHUNK + KG_MAXC);
     for (u32 i = threadIdx.x; E0 + i < Eend; i += KG_THREADS) s_idx[i] = newidx[src_of_tag(tag_of(vals[E0 + i]))];
     __syncthreads();
+    __shared__ u32 s_big[KG_CHUNK / KG_COOP + 8], s_nbig;
+    if (threadIdx.x == 0) s_nbig = 0;
+    // one group of key r: block `cur`, members lo | hi.  The key's first group goes to the per-key arrays, the
+    // others are parked at the key's entry positions (every lane of a cooperating wave counts, one stores).
+    auto emit = [&](const u32 r, const u32 fa, const u32 cur, const unsigned long long lo, const unsigned long long hi,
+                    u32& groups, u32& bigs, u32& parked, const bool store) {
+        const u32 cnt = __popcll(lo) + __popcll(hi);
+        u32 inf;
+        if (cnt <= INLINE_MAX) {
+            inf = (cnt - 1) << 29;
+            unsigned long long a = lo, bq = hi;
+            for (u32 j = 0; j < cnt; ++j) {   // local ids, ascending, 7 bits each
+                u32 id;
+                if (a) { id = __ffsll((long long)a) - 1; a &= a - 1; }
+                else { id = 64 + __ffsll((long long)bq) - 1; bq &= bq - 1; }
+                inf |= id << (7 * j);
+            }
+        } else {
+            const uint4 mask = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
+            if (groups == 0) { if (store) mask0[r] = mask; inf = BIG; }
+            else { const u32 slot = fa / 4 + parked; if (store) tmp_mask[slot] = mask; inf = BIG | slot; ++parked; }
+            ++bigs;
+        }
+        if (store) {
+            if (groups == 0) { blk0[r] = cur; info0[r] = inf; }
+            else { tmp_blk[fa + groups] = cur; tmp_info[fa + groups] = inf; }
+        }
+        ++groups;
+    };
+    __syncthreads();
     for (u32 r = r_lo + threadIdx.x; r < r_hi; r += KG_THREADS) {
         const u32 fa = first[r], c = first[r + 1] - fa, f0 = fa - E0;
         if (c > KG_MAXC) {
             *ovf = 1;
             gsum[r] = 0;
+            continue;
+        }
+        if (c > coop) {   // many holders: a whole wave walks this key (below)
+            s_big[atomicAdd(&s_nbig, 1u)] = r;
             continue;
         }
         if (W && c) wkey[r] = weight_of(vals[fa]);
@@ -600,29 +634,41 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
                     } else if (b >= floor_b && b != b0 && b < nxt) nxt = b;
                 }
             }
-            const u32 cnt = __popcll(lo) + __popcll(hi);
-            u32 inf;
-            if (cnt <= INLINE_MAX) {
-                inf = (cnt - 1) << 29;
-                unsigned long long a = lo, bq = hi;
-                for (u32 j = 0; j < cnt; ++j) {   // local ids, ascending, 7 bits each
-                    u32 id;
-                    if (a) { id = __ffsll((long long)a) - 1; a &= a - 1; }
-                    else { id = 64 + __ffsll((long long)bq) - 1; bq &= bq - 1; }
-                    inf |= id << (7 * j);
-                }
-            } else {
-                const uint4 mask = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
-                if (groups == 0) { mask0[r] = mask; inf = BIG; }
-                else { const u32 slot = fa / 4 + parked; tmp_mask[slot] = mask; inf = BIG | slot; ++parked; }
-                ++bigs;
-            }
-            if (groups == 0) { blk0[r] = cur; info0[r] = inf; }
-            else { tmp_blk[fa + groups] = cur; tmp_info[fa + groups] = inf; }
-            ++groups;
+            emit(r, fa, cur, lo, hi, groups, bigs, parked, true);
             cur = nxt;
         }
         gsum[r] = (u64)groups | ((u64)bigs << 32);
+    }
+    __syncthreads();
+    // keys with many holders, one wave each: the lanes share the walk, the masks and the next block are reduced
+    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (u32 q = wv; q < s_nbig; q += KG_THREADS / 64) {
+        const u32 r = s_big[q];
+        const u32 fa = first[r], c = first[r + 1] - fa, f0 = fa - E0;
+        if (W && lane == 0) wkey[r] = weight_of(vals[fa]);
+        const u32 b0 = s_idx[f0] / TB;
+        u32 cur = b0;
+        u32 groups = 0, bigs = 0, parked = 0;
+        while (cur != ~0u) {
+            u32 nxt = ~0u;
+            unsigned long long lo = 0, hi = 0;
+            const u32 floor_b = groups == 0 ? 0u : cur + 1;
+            for (u32 i = lane; i < c; i += 64) {
+                const u32 t = s_idx[f0 + i], b = t / TB;
+                if (b == cur) {
+                    const u32 l = t % TB;
+                    if (l < 64) lo |= 1ull << l; else hi |= 1ull << (l - 64);
+                } else if (b >= floor_b && b != b0 && b < nxt) nxt = b;
+            }
+            for (int o = 32; o; o >>= 1) {
+                lo |= __shfl_xor(lo, o);
+                hi |= __shfl_xor(hi, o);
+                nxt = min(nxt, (u32)__shfl_xor(nxt, o));
+            }
+            emit(r, fa, cur, lo, hi, groups, bigs, parked, lane == 0);
+            cur = nxt;
+        }
+        if (lane == 0) gsum[r] = (u64)groups | ((u64)bigs << 32);
     }
 }
 // the parked records to their places in rank order (goff = exclusive scan of gsum): block, rank << 32 |
