@@ -280,6 +280,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     const u64* keys_in = d_keys;
     const V* tags_in = VA;
     u64 nw = n;
+    int topbit = kbits;   // the bucket partition takes the bits just below this one
     if (e->nparts > 1) {
         // equal shares of [0, largest key] (or of [0, 2^key_bits) when the caller fixed key_bits)
         const unsigned __int128 span = e->have_max_key ? (unsigned __int128)e->max_key + 1
@@ -287,6 +288,10 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                                                        : ((unsigned __int128)1 << kbits);
         const u64 lo = (u64)((span * e->part_id) / e->nparts);
         const u64 hi = (u64)((span * (e->part_id + 1)) / e->nparts - 1);
+        // a slice spans hi - lo: the bits below that width spread its keys evenly over the buckets (the bits
+        // above take at most two values inside the slice; the buckets compare whole keys anyway)
+        topbit = 1;
+        while (topbit < kbits && ((hi - lo) >> topbit)) ++topbit;
         u32* first = (u32*)e->KB.p;                 // N
         u32* cnt = (u32*)e->KB.p + (N + 2);         // N
         u32* fpos = (u32*)e->KB.p + 2 * ((size_t)N + 2);   // N   (KB holds 2(n+4) u32 >= 3(N+2) whenever n >= 2N; checked below)
@@ -324,20 +329,20 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     // 400-800 entries for uniform hashes (up to twice that when the keys span just over half of [0, 2^kbits))
     int pb = 0;
     // (bit ranges ending at bit 64: only far above the sizes at which the rocPRIM issue below shows)
-    if (phase == 0 && !e->hash_off && !e->full_sort && nw >= (kbits < 64 ? 4096u : (1u << 23))) {
+    if ((phase == 0 || phase == 1) && !e->hash_off && !e->full_sort && nw >= (topbit < 64 ? 4096u : (1u << 23))) {
         pb = 1;
         while ((nw >> pb) > HB_MEAN) ++pb;
-        if (pb > kbits) pb = 0;   // (few distinct keys, many holders each: the sort path)
+        if (pb > topbit) pb = 0;   // (few distinct keys, many holders each: the sort path)
     }
     if ((rc = e->FK.ensure((nw / 2 + 16) * 4))) return rc;
     u32* first = (u32*)e->FK.p;            // first kept entry of every rank (FK: the slice's input keys are dead after sort 1)
     if (pb) {
-        const int shiftb = kbits - pb;
+        const int shiftb = topbit - pb;
         const u32 nbuckets = 1u << pb;
-        KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, KA, tags_in, VB, nw, shiftb, kbits, st));
+        KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, KA, tags_in, VB, nw, shiftb, topbit, st));
         if ((rc = e->tmp.ensure(tb))) return rc;
         KSP_HIP(hipEventRecord(e->ev[4], st));
-        KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, keys_in, KA, tags_in, VB, nw, shiftb, kbits, st));
+        KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, keys_in, KA, tags_in, VB, nw, shiftb, topbit, st));
         KSP_HIP(hipEventRecord(e->ev[5], st));
         e->sort_entries = nw;
         e->sort_bits = pb;

@@ -300,7 +300,7 @@ __global__ void k_bucket_bounds(const u64* __restrict__ keys, u64 n, int shiftb,
     if (b == nbuckets) lo = n;
     while (lo < hi) {
         const u64 mid = lo + ((hi - lo) >> 1);
-        if ((keys[mid] >> shiftb) < (u64)b) lo = mid + 1; else hi = mid;
+        if (((keys[mid] >> shiftb) & (u64)(nbuckets - 1)) < (u64)b) lo = mid + 1; else hi = mid;   // (the partition's digit)
     }
     bstart[b] = (u32)lo;
 }
