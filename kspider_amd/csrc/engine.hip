@@ -6,12 +6,13 @@
 // (PAIRS_COUNTER, :22-27).  Here the per-source hash sets live in HBM as sorted
 // uint64 runs and the N x N shared-k-mer matrix is produced tile by tile:
 //
-//   stage 1 (build_blocks / build_postings; kernels in stage1_kernels.hip.h)  every 64-bit hash is
-//            replaced by its dense rank among the hashes held by at least two sources (exact, order
-//            preserving, 32 bit); sources that share keys are moved next to each other (label pass);
-//            the entries of each block of TB = 128 sources are merged into ONE sorted list of distinct
-//            ranks with postings (which of the 128 sources hold the key); a bitmap says which block
-//            pairs share a key at all.
+//   stage 1 (build_blocks / build_postings; kernels in stage1_kernels.hip.h)  equal hashes are brought
+//            together (partition by the top key bits + LDS hash buckets; or a prefix sort) and every hash
+//            held by at least two sources is replaced by a dense 32-bit rank (exact: equal hash <=> equal
+//            rank); sources that share keys are moved next to each other (label pass); the holders of
+//            every key are cut into blocks of TB = 128 sources, which gives ONE sorted list of distinct
+//            ranks per block with postings (which of the 128 sources hold the key); a bitmap says which
+//            block pairs share a key at all.
 //   stage 2 (k_join; join_kernels.hip.h)  a work list of the active tiles, cut into shares by estimated
 //            work.  A share searches rank-aligned cells of the two lists (4-ary tree in LDS) and
 //            accumulates the matches — in LDS pair counters (weighted input, single-source postings) or
