@@ -328,9 +328,11 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     tb = 0;
     // grouping by hash bucket (see k_bucket_group): partition on the top pb key bits only — buckets of
     // 400-800 entries for uniform hashes (up to twice that when the keys span just over half of [0, 2^kbits))
+    // (never a bit range that ends at bit 64 — see the rocPRIM note below: bit 63 is left to the buckets,
+    //  which compare whole keys; folding the two halves of the key range keeps the buckets even)
+    if (topbit > 63) topbit = 63;
     int pb = 0;
-    // (bit ranges ending at bit 64: only far above the sizes at which the rocPRIM issue below shows)
-    if ((phase == 0 || phase == 1) && !e->hash_off && !e->full_sort && nw >= (topbit < 64 ? 4096u : (1u << 23))) {
+    if ((phase == 0 || phase == 1) && !e->hash_off && !e->full_sort && nw >= 4096u) {
         pb = 1;
         while ((nw >> pb) > HB_MEAN) ++pb;
         if (pb > topbit) pb = 0;   // (few distinct keys, many holders each: the sort path)

@@ -150,6 +150,21 @@ def test_bucket_grouping_and_its_fallback(oracle_lib, mode):
         assert 0 < st["sort_bits"] <= 16, st["sort_bits"]        # partitioned, not sorted
     else:
         assert st["sort_bits"] >= 32
+    # full 64-bit hashes (the partition skips bit 63) with the largest key — the hash table's "empty" pattern —
+    # and its neighbours held by many sources
+    top = np.uint64(0xFFFFFFFFFFFFFFFF)
+    runs = []
+    for s_ in range(120):
+        wide = rng.integers(0, 1 << 64, size=60, dtype=np.uint64)
+        extra = [top] if s_ % 2 == 0 else [top - np.uint64(1)]
+        if s_ % 3 == 0:
+            extra.append(np.uint64(0))
+        if s_ % 5 == 0:
+            extra.append(np.uint64(1) << np.uint64(63))
+        runs.append(np.unique(np.concatenate([wide, np.array(extra, dtype=np.uint64)])))
+    _, st = _check(synth.from_runs(runs), oracle_lib)
+    if mode != "sort_grouping":
+        assert 0 < st["sort_bits"] <= 16, st["sort_bits"]
     # 6000 distinct keys under one 30-bit prefix, among uniform ones
     crowd = (np.uint64(0x2345678) << np.uint64(30)) | rng.integers(0, 1 << 30, size=6000, dtype=np.uint64)
     runs = []
