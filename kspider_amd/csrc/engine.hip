@@ -1348,6 +1348,15 @@ int ksp_engine_get_stats(const ksp_engine* e, ksp_stats* out) {
     return KSP_OK;
 }
 
+// (diagnostics) engine index of every source after the reordering: block = index / 128
+int ksp_engine_source_order(const ksp_engine* e, uint32_t* h_newidx /* n_sources */) {
+    if (!e || !h_newidx) return KSP_E_ARG;
+    if (!e->n_sources || !e->smap.p) return KSP_OK;
+    const size_t NN = ((size_t)e->n_sources + 64) & ~(size_t)63;
+    KSP_HIP(hipMemcpy(h_newidx, e->smap.as<u32>() + 4 * NN, (size_t)e->n_sources * 4, hipMemcpyDeviceToHost));
+    return KSP_OK;
+}
+
 int ksp_engine_block_key_counts(const ksp_engine* e, uint32_t* h_blk_off /* nb+1 */) {
     if (!e || !h_blk_off) return KSP_E_ARG;
     if (!e->nb || !e->n_entries) return KSP_OK;

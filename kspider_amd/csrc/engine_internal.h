@@ -14,5 +14,6 @@ void set_error(const std::string& s);
 extern "C" {
 /* test/diagnostic hook: distinct-key offsets of the block lists (nb + 1 values). */
 int ksp_engine_block_key_counts(const ksp_engine* e, uint32_t* h_blk_off);
+int ksp_engine_source_order(const ksp_engine* e, uint32_t* h_newidx);   // (diagnostics) engine index of every source
 }
 #endif

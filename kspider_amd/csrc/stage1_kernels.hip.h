@@ -982,7 +982,9 @@ __global__ void k_tile_flags(const u32* __restrict__ pr, const u32* __restrict__
 __global__ void k_pack_flags(const unsigned char* __restrict__ flags, u64 n, u32* __restrict__ bits) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;   // blockDim is a multiple of 64
     const unsigned long long m = __ballot(t < n && flags[t] != 0);
-    if ((threadIdx.x & 63) == 0) { bits[t >> 5] = (u32)m; bits[(t >> 5) + 1] = (u32)(m >> 32); }
+    // (only waves that hold tiles write: the grid is rounded up to whole workgroups, and the words behind the
+    //  bitmap are the flags of the first tiles — a trailing wave used to zero them while the first wave read them)
+    if ((threadIdx.x & 63) == 0 && t < n) { bits[t >> 5] = (u32)m; bits[(t >> 5) + 1] = (u32)(m >> 32); }
 }
 
 // ---- key-range slices (multi-GPU build) -----------------------------------------------

@@ -2,6 +2,8 @@
 
 Bit-exact bar: integer pair counts, identical edge sets.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -178,6 +180,39 @@ def test_bucket_grouping_and_its_fallback(oracle_lib, mode):
             for _ in range(3500)]
     _, st = _check(synth.from_runs(runs), oracle_lib)
     assert st["sort_bits"] >= 32
+
+
+def test_active_tiles_are_exactly_the_block_pairs_that_share_a_key(oracle_lib, monkeypatch):
+    """In the caller's order (KSP_REORDER=0) the blocks are source // 128, so the work list can be checked
+    against the sketches: a tile is active iff its two blocks share a key (diagonal: a key with two holders
+    in the block).  (The bitmap's first tiles once lost their flags to a trailing wave of k_pack_flags.)"""
+    monkeypatch.setenv("KSP_REORDER", "0")
+    rng = np.random.default_rng(41)
+    for n, share in ((300, 0.02), (1100, 0.004), (2300, 0.0015)):
+        pool = rng.integers(0, 1 << 60, size=4000, dtype=np.uint64)
+        runs = [np.unique(np.concatenate([rng.integers(0, 1 << 60, size=30, dtype=np.uint64),
+                                          pool[rng.random(pool.size) < share]])) for _ in range(n)]
+        sk = synth.from_runs(runs)
+        _, st = _check(sk, oracle_lib)
+        if os.environ.get("KSP_NO_SCHED"):
+            continue
+        src = np.repeat(np.arange(n), np.diff(sk.offsets).astype(np.int64))
+        order = np.argsort(sk.keys, kind="stable")
+        ks, bs = sk.keys[order], (src[order] // 128)
+        want = set()
+        bounds = np.flatnonzero(np.diff(ks)) + 1
+        for grp in np.split(bs, bounds):
+            if grp.size < 2:
+                continue
+            u, c = np.unique(grp, return_counts=True)
+            for x in range(u.size):
+                if c[x] >= 2:
+                    want.add((int(u[x]), int(u[x])))
+                for y in range(x + 1, u.size):
+                    want.add((int(u[x]), int(u[y])))
+        nb = (n + 127) // 128
+        if st["n_active_tiles"] != nb * (nb + 1) // 2:      # (mostly-dense inputs walk all tiles)
+            assert st["n_active_tiles"] == len(want), (n, st["n_active_tiles"], len(want))
 
 
 def test_rank_skew_takes_the_oversized_cell_path(oracle_lib):
