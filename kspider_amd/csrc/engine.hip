@@ -447,10 +447,11 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         u32* tmp_blk = (u32*)e->KB.p;         // records parked at entry positions (KB: free since the grouping by key)
         u32* tmp_info = tmp_blk + (m + 2);
         // gm: per key the mask, block and posting word of its first group, then the parked masks of further groups
-        if ((rc = e->gm.ensure(((size_t)U + 4) * 24 + ((size_t)m / 4 + 4) * 16))) return rc;
+        if ((rc = e->gm.ensure(((size_t)U + 4) * 24 + ((size_t)m / 4 + 4) * 16 + KG_HUGE_CAP * 4))) return rc;
         uint4* mask0 = e->gm.as<uint4>();
         uint4* tmp_mask = mask0 + (U + 4);
         u32 *blk0 = (u32*)(tmp_mask + (m / 4 + 4)), *info0 = blk0 + (U + 4);
+        u32* huge_list = nb <= KG_HUGE_NB ? info0 + (U + 4) : nullptr;   // keys with more than KG_MAXC holders
         u32* wkey = W ? (u32*)VB : nullptr;   // (VB: the partitioned tags are dead)
         u32* d_kovf = (u32*)(scal + 11);
         const u32 chunks = (u32)((m + KG_CHUNK - 1) / KG_CHUNK);
@@ -458,7 +459,11 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input — are visited by no chunk)
         hipLaunchKernelGGL((k_key_groups<V, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, rank1, firstp, newidx, (u32)m, U,
                            gsum, blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf,
-                           std::getenv("KSP_DEBUG_COOP") ? std::max<u32>(KG_COOP, (u32)std::atoi(std::getenv("KSP_DEBUG_COOP"))) : KG_COOP);   // (timing experiments: raise the wave-per-key threshold)
+                           std::getenv("KSP_DEBUG_COOP") ? std::max<u32>(KG_COOP, (u32)std::atoi(std::getenv("KSP_DEBUG_COOP"))) : KG_COOP,   // (timing experiments: raise the wave-per-key threshold)
+                           huge_list);
+        if (huge_list)
+            hipLaunchKernelGGL((k_key_groups_huge<V, W>), dim3(KG_HUGE_CAP), dim3(256), 0, st, VA, firstp, newidx, nb, gsum, blk0,
+                               info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf, huge_list);
         tb = 0;
         KSP_HIP(rocprim::exclusive_scan(nullptr, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
         if ((rc = e->tmp.ensure(tb))) return rc;

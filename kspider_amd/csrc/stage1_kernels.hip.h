@@ -547,9 +547,11 @@ struct PruneScatterIt {
 // first group of key r (for most keys the only one) in per-key arrays at index r, further groups at the
 // key's own entry positions (block and posting word at first[r] + j, masks at first[r]/4 + j).
 // gsum[r] = groups | masks << 32; after the scan k_move_groups packs the records in rank order.
-// Keys with more than KG_MAXC holders do not fit the staging: they raise *ovf and the build takes the
-// sort-by-block path instead.
+// Keys with more than KG_MAXC holders do not fit the staging: they are listed for k_key_groups_huge; only
+// when that cannot take them (more than KG_HUGE_NB blocks, or more than KG_HUGE_CAP such keys) *ovf is
+// raised and the build takes the sort-by-block path instead.
 constexpr u32 KG_CHUNK = 4096, KG_MAXC = 2048, KG_THREADS = 256, KG_COOP = 64;
+constexpr u32 KG_HUGE_CAP = 4096, KG_HUGE_NB = 2048;   // keys with more than KG_MAXC holders per build / blocks their LDS table holds
 
 template <class V, bool W>
 __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__ vals, const u32* __restrict__ rank,
@@ -558,7 +560,8 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
                                                            u32* __restrict__ blk0, u32* __restrict__ info0,
                                                            uint4* __restrict__ mask0, u32* __restrict__ tmp_blk,
                                                            u32* __restrict__ tmp_info, uint4* __restrict__ tmp_mask,
-                                                           u32* __restrict__ wkey, u32* __restrict__ ovf, const u32 coop) {
+                                                           u32* __restrict__ wkey, u32* __restrict__ ovf, const u32 coop,
+                                                           u32* __restrict__ huge_list) {
     __shared__ u32 s_idx[KG_CHUNK + KG_MAXC + 4];
     const u32 E0 = blockIdx.x * KG_CHUNK, E1 = min(m, E0 + KG_CHUNK);
     // the keys that start inside [E0, E1)
@@ -602,9 +605,9 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
     __syncthreads();
     for (u32 r = r_lo + threadIdx.x; r < r_hi; r += KG_THREADS) {
         const u32 fa = first[r], c = first[r + 1] - fa, f0 = fa - E0;
-        if (c > KG_MAXC) {
-            *ovf = 1;
-            gsum[r] = 0;
+        if (c > KG_MAXC) {   // does not fit the staging: left to k_key_groups_huge (ovf[1] counts them)
+            const u32 q = huge_list ? atomicAdd(&ovf[1], 1u) : KG_HUGE_CAP;
+            if (q < KG_HUGE_CAP) huge_list[q] = r; else ovf[0] = 1;
             continue;
         }
         if (c > coop) {   // many holders: a whole wave walks this key (below)
@@ -670,6 +673,83 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
         }
         if (lane == 0) gsum[r] = (u64)groups | ((u64)bigs << 32);
     }
+}
+// Keys with more than KG_MAXC holders (conserved k-mers of a large same-species collection), one workgroup
+// each: the holders are read from global memory once and OR-ed into an LDS table of 128-bit masks, one per
+// block (up to KG_HUGE_NB blocks); the non-empty blocks, ascending, are the key's groups.  Same parked
+// record format as k_key_groups.
+template <class V, bool W>
+__global__ __launch_bounds__(256) void k_key_groups_huge(const V* __restrict__ vals, const u32* __restrict__ first,
+                                                         const u32* __restrict__ newidx, const u32 nb,
+                                                         u64* __restrict__ gsum, u32* __restrict__ blk0,
+                                                         u32* __restrict__ info0, uint4* __restrict__ mask0,
+                                                         u32* __restrict__ tmp_blk, u32* __restrict__ tmp_info,
+                                                         uint4* __restrict__ tmp_mask, u32* __restrict__ wkey,
+                                                         const u32* __restrict__ ovf, const u32* __restrict__ huge_list) {
+    __shared__ u32 tab[KG_HUGE_NB * 4];
+    __shared__ u32 s_part[4], s_g0big;
+    if (blockIdx.x >= min(ovf[1], KG_HUGE_CAP)) return;
+    const u32 r = huge_list[blockIdx.x];
+    const u32 fa = first[r], c = first[r + 1] - fa;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (u32 i = tid; i < nb * 4; i += 256) tab[i] = 0;
+    if (tid == 0) s_g0big = 0;
+    __syncthreads();
+    for (u32 i = tid; i < c; i += 256) {
+        const u32 t = newidx[src_of_tag(tag_of(vals[fa + i]))];
+        atomicOr(&tab[(t / TB) * 4 + ((t % TB) >> 5)], 1u << (t & 31));
+    }
+    if (W && tid == 0) wkey[r] = weight_of(vals[fa]);
+    __syncthreads();
+    // every thread owns a contiguous range of blocks (ascending order is kept); groups | bigs << 16, scanned
+    const u32 per = (nb + 255) / 256, b_lo = tid * per, b_hi = min(nb, b_lo + per);
+    u32 mine = 0;
+    for (u32 b = b_lo; b < b_hi; ++b) {
+        const u32 cnt = __popc(tab[b * 4]) + __popc(tab[b * 4 + 1]) + __popc(tab[b * 4 + 2]) + __popc(tab[b * 4 + 3]);
+        if (cnt) mine += 1u + ((cnt > INLINE_MAX) << 16);
+    }
+    u32 inc = mine;
+    for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+    if (lane == 63) s_part[wv] = inc;
+    __syncthreads();
+    u32 run = inc - mine;
+    for (u32 w = 0; w < wv; ++w) run += s_part[w];
+    // is the key's first group one with a mask?  (its mask goes to the per-key array, not to a parked slot)
+    if ((run & 0xFFFFu) == 0 && (mine & 0xFFFFu)) {
+        for (u32 b = b_lo; b < b_hi; ++b) {
+            const u32 cnt = __popc(tab[b * 4]) + __popc(tab[b * 4 + 1]) + __popc(tab[b * 4 + 2]) + __popc(tab[b * 4 + 3]);
+            if (cnt) { s_g0big = cnt > INLINE_MAX; break; }
+        }
+    }
+    __syncthreads();
+    const u32 g0big = s_g0big;
+    u32 j = run & 0xFFFFu, bigs = run >> 16;
+    for (u32 b = b_lo; b < b_hi; ++b) {
+        const u32 m0 = tab[b * 4], m1 = tab[b * 4 + 1], m2 = tab[b * 4 + 2], m3 = tab[b * 4 + 3];
+        const u32 cnt = __popc(m0) + __popc(m1) + __popc(m2) + __popc(m3);
+        if (!cnt) continue;
+        u32 inf;
+        if (cnt <= INLINE_MAX) {
+            inf = (cnt - 1) << 29;
+            unsigned long long a = (unsigned long long)m0 | ((unsigned long long)m1 << 32);
+            unsigned long long bq = (unsigned long long)m2 | ((unsigned long long)m3 << 32);
+            for (u32 q = 0; q < cnt; ++q) {
+                u32 id;
+                if (a) { id = __ffsll((long long)a) - 1; a &= a - 1; }
+                else { id = 64 + __ffsll((long long)bq) - 1; bq &= bq - 1; }
+                inf |= id << (7 * q);
+            }
+        } else {
+            const uint4 mask = make_uint4(m0, m1, m2, m3);
+            if (j == 0) { mask0[r] = mask; inf = BIG; }
+            else { const u32 slot = fa / 4 + (bigs - g0big); tmp_mask[slot] = mask; inf = BIG | slot; }
+            ++bigs;
+        }
+        if (j == 0) { blk0[r] = b; info0[r] = inf; }
+        else { tmp_blk[fa + j] = b; tmp_info[fa + j] = inf; }
+        ++j;
+    }
+    if (tid == 255) gsum[r] = (u64)j | ((u64)bigs << 32);   // (the last thread's running totals are the key's totals)
 }
 // the parked records to their places in rank order (goff = exclusive scan of gsum): block, rank << 32 |
 // posting word, rank; masks to their final index.  With `work` set (at most KG_WORK blocks) the kernel also

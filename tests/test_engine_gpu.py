@@ -182,6 +182,21 @@ def test_bucket_grouping_and_its_fallback(oracle_lib, mode):
     assert st["sort_bits"] >= 32
 
 
+def test_keys_with_thousands_of_holders(oracle_lib):
+    """Conserved keys of a large same-species collection: more holders than the key-by-key list build stages
+    in LDS (2 048) — one workgroup per such key ORs the holders into per-block masks."""
+    rng = np.random.default_rng(43)
+    n = 2600
+    everywhere = rng.integers(0, 1 << 58, size=3, dtype=np.uint64)
+    most = rng.integers(0, 1 << 58, size=4, dtype=np.uint64)
+    runs = []
+    for s_ in range(n):
+        own = rng.integers(0, 1 << 58, size=6, dtype=np.uint64)
+        keep = most[rng.random(most.size) < 0.85]
+        runs.append(np.unique(np.concatenate([own, everywhere, keep])))
+    _check(synth.from_runs(runs), oracle_lib)
+
+
 def test_active_tiles_are_exactly_the_block_pairs_that_share_a_key(oracle_lib, monkeypatch):
     """In the caller's order (KSP_REORDER=0) the blocks are source // 128, so the work list can be checked
     against the sketches: a tile is active iff its two blocks share a key (diagonal: a key with two holders
