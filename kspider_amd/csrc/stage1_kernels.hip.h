@@ -292,6 +292,7 @@ constexpr u32 HB_THREADS = 512;
 constexpr u32 HB_MEAN = 800;
 constexpr u32 HB_KEPT = 1u << 31, HB_FIRST = 1u << 30;   // per-entry record: kept | first of its key | rank << 12 | place
 constexpr u32 HB_EMIT = 8;       // buckets per workgroup of the emit kernel
+constexpr u32 HB_BIG_CAP = 1024, HB_BIG_DISTINCT = 3072;   // k_bucket_big: buckets per build / distinct keys per bucket
 
 __global__ void k_bucket_bounds(const u64* __restrict__ keys, u64 n, int shiftb, u32 nbuckets, u32* __restrict__ bstart) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -310,7 +311,8 @@ __global__ void k_bucket_bounds(const u64* __restrict__ keys, u64 n, int shiftb,
 // of memory round trips otherwise).  bsum[] is zero at launch (trailing empty buckets are not visited).
 __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __restrict__ keys, const u32* __restrict__ bstart,
                                                              u32 nbuckets, u32 nw, u32* __restrict__ rec,
-                                                             u64* __restrict__ bsum, u32* __restrict__ overflow) {
+                                                             u64* __restrict__ bsum, u32* __restrict__ overflow,
+                                                             u32* __restrict__ big_list) {
     constexpr u32 NT = HB_THREADS, NWV = NT / 64;
     __shared__ unsigned long long tkey[HB_SLOTS + 1];
     __shared__ u32 tcnt2[HB_SLOTS / 2 + 1];   // entries per key, two 16-bit counters per word
@@ -328,12 +330,15 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
     u32 b = blockIdx.x;
     u32 b0 = nw, raw = 0;
     if (b < nbuckets) { b0 = bstart[b]; raw = bstart[b + 1] - b0; }
-    u32 size = raw > HB_CAP ? 0 : raw;   // a bucket that does not fit is skipped: the host falls back to the sort path
+    u32 size = raw > HB_CAP ? 0 : raw;   // a bucket that does not fit is skipped here: k_bucket_big takes it
     unsigned long long mykey[EPT], nkey[EPT];
 #pragma unroll
     for (u32 j = 0; j < EPT; ++j) mykey[j] = tid + j * NT < size ? keys[b0 + tid + j * NT] : 0;
     while (b < nbuckets && b0 < nw) {   // (b0 == nw: this bucket and every later one is empty)
-        if (raw > HB_CAP && tid == 0) *overflow = 1;
+        if (raw > HB_CAP && tid == 0) {   // left to k_bucket_big (overflow[1] counts them)
+            const u32 q = atomicAdd(&overflow[1], 1u);
+            if (q < HB_BIG_CAP) big_list[q] = b; else overflow[0] = 1;
+        }
         const u32 bn = b + gridDim.x;
         u32 n0 = nw, nraw = 0;          // bounds of the next bucket
         if (bn < nbuckets) { n0 = bstart[bn]; nraw = bstart[bn + 1] - n0; }
@@ -410,6 +415,91 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
 #pragma unroll
         for (u32 j = 0; j < EPT; ++j) mykey[j] = nkey[j];
         __syncthreads();   // the table is rebuilt from here on
+    }
+}
+
+// Buckets above HB_CAP entries — a key held by thousands of sources lands in one — one workgroup each, with no
+// per-entry state in LDS: the bucket's keys are streamed from global memory twice (count, then place).  PART 0
+// leaves the bucket's totals in bsum[] before the scan over the buckets; PART 1, after it, groups again and
+// writes tags, ranks and first[] straight to their final places.  More than HB_BIG_DISTINCT distinct keys in
+// such a bucket (thousands of keys under one prefix) is the one case left for the sort path (*overflow).
+template <class V, int PART>
+__global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict__ keys, const V* __restrict__ vals,
+                                                           const u32* __restrict__ bstart, const u32* __restrict__ big_list,
+                                                           u32* __restrict__ overflow, u64* __restrict__ bsum,
+                                                           const u64* __restrict__ bbase, V* __restrict__ vals2,
+                                                           u32* __restrict__ rank2, u32* __restrict__ first) {
+    constexpr u32 NT = HB_THREADS, NWV = NT / 64;
+    constexpr unsigned long long EMPTY = ~0ull;
+    __shared__ unsigned long long tkey[HB_SLOTS + 1];
+    __shared__ u32 tcnt[HB_SLOTS + 1], toff[HB_SLOTS + 1], trank[HB_SLOTS + 1], tfill[HB_SLOTS + 1];
+    __shared__ u32 wpe[NWV], wpk[NWV], s_distinct;
+    if (blockIdx.x >= min(overflow[1], HB_BIG_CAP)) return;
+    const u32 b = big_list[blockIdx.x];
+    const u32 b0 = bstart[b], size = bstart[b + 1] - b0;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (u32 i = tid; i <= HB_SLOTS; i += NT) { tkey[i] = EMPTY; tcnt[i] = 0; tfill[i] = 0; }
+    if (tid == 0) s_distinct = 0;
+    __syncthreads();
+    auto slot_of = [&](const unsigned long long key, const bool insert) -> u32 {
+        if (key == EMPTY) return HB_SLOTS;
+        u32 h = (u32)((key * 0x9E3779B97F4A7C15ull) >> 52) & (HB_SLOTS - 1);
+        while (true) {
+            if (insert) {
+                const unsigned long long prev = atomicCAS(&tkey[h], EMPTY, key);
+                if (prev == EMPTY) { atomicAdd(&s_distinct, 1u); return h; }
+                if (prev == key) return h;
+                if (s_distinct > HB_BIG_DISTINCT) return HB_SLOTS;   // (the table is filling up: given up below)
+            } else if (tkey[h] == key) return h;
+            h = (h + 1) & (HB_SLOTS - 1);
+        }
+    };
+    for (u32 i = tid; i < size; i += NT) atomicAdd(&tcnt[slot_of(keys[b0 + i], true)], 1u);
+    __syncthreads();
+    if (s_distinct > HB_BIG_DISTINCT) {   // too many distinct keys for the table: the sort path
+        if (tid == 0) *overflow = 1;
+        return;
+    }
+    // exclusive scan over the slots: kept entries, kept keys
+    constexpr u32 PER = (HB_SLOTS + 1 + NT - 1) / NT;
+    u32 me = 0, mk = 0;
+    for (u32 j = 0; j < PER; ++j) {
+        const u32 sl = tid * PER + j;
+        const u32 c = sl <= HB_SLOTS ? tcnt[sl] : 0;
+        if (c >= 2) { me += c; ++mk; }
+    }
+    u32 ie = me, ik = mk;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 ue = __shfl_up(ie, o), uk = __shfl_up(ik, o);
+        if (lane >= o) { ie += ue; ik += uk; }
+    }
+    if (lane == 63) { wpe[wv] = ie; wpk[wv] = ik; }
+    __syncthreads();
+    u32 re = ie - me, rk = ik - mk, te = 0, tk = 0;
+    for (u32 w = 0; w < NWV; ++w) { if (w < (u32)wv) { re += wpe[w]; rk += wpk[w]; } te += wpe[w]; tk += wpk[w]; }
+    if (PART == 0) {
+        if (tid == 0) bsum[b] = (u64)te | ((u64)tk << 32);
+        return;
+    }
+    for (u32 j = 0; j < PER; ++j) {
+        const u32 sl = tid * PER + j;
+        if (sl > HB_SLOTS) break;
+        const u32 c = tcnt[sl];
+        toff[sl] = re; trank[sl] = rk;
+        if (c >= 2) { re += c; ++rk; }
+    }
+    __syncthreads();
+    const u64 base = bbase[b];
+    const u32 ebase = (u32)base, kbase = (u32)(base >> 32);
+    for (u32 i = tid; i < size; i += NT) {
+        const u32 sl = slot_of(keys[b0 + i], false);
+        if (tcnt[sl] >= 2) {
+            const u32 fill = atomicAdd(&tfill[sl], 1u);
+            const u32 p = ebase + toff[sl] + fill, r = kbase + trank[sl];
+            vals2[p] = vals[b0 + i];
+            rank2[p] = r;
+            if (fill == 0) first[r] = p;
+        }
     }
 }
 
