@@ -368,7 +368,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         u32* big_list = bstart + (nbuckets + 1);   // buckets above HB_CAP entries (d_hovf[1] counts them)
         hipLaunchKernelGGL(k_bucket_group, dim3(std::min(nbuckets, e->hb_slots)), dim3(HB_THREADS), 0, st, KA, bstart,
                            nbuckets, (u32)nw, rec, bsum, d_hovf, big_list);
-        hipLaunchKernelGGL((k_bucket_big<V, 0>), dim3(HB_BIG_CAP), dim3(HB_THREADS), 0, st, KA, VB, bstart, big_list, d_hovf,
+        hipLaunchKernelGGL((k_bucket_big<V, 0>), dim3(128), dim3(HB_THREADS), 0, st, KA, VB, bstart, big_list, d_hovf,
                            bsum, (const u64*)nullptr, VA, rank1, first);
         size_t tb2 = 0;
         KSP_HIP(rocprim::exclusive_scan(nullptr, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
@@ -376,7 +376,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
         hipLaunchKernelGGL((k_bucket_emit<V>), dim3((nbuckets + HB_EMIT - 1) / HB_EMIT), dim3(HB_THREADS), 0, st, rec, VB, bstart,
                            bbase, bsum, nbuckets, VA, rank1, first, scal);
-        hipLaunchKernelGGL((k_bucket_big<V, 1>), dim3(HB_BIG_CAP), dim3(HB_THREADS), 0, st, KA, VB, bstart, big_list, d_hovf,
+        hipLaunchKernelGGL((k_bucket_big<V, 1>), dim3(128), dim3(HB_THREADS), 0, st, KA, VB, bstart, big_list, d_hovf,
                            bsum, bbase, VA, rank1, first);
         KSP_HIP(hipMemcpyAsync(e->h_scal + 2, scal + 2, 8, hipMemcpyDeviceToHost, st));
         KSP_HIP(hipMemcpyAsync(e->h_scal + 6, scal + 6, 8, hipMemcpyDeviceToHost, st));
@@ -467,7 +467,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                            std::getenv("KSP_DEBUG_COOP") ? std::max<u32>(KG_COOP, (u32)std::atoi(std::getenv("KSP_DEBUG_COOP"))) : KG_COOP,   // (timing experiments: raise the wave-per-key threshold)
                            huge_list);
         if (huge_list)
-            hipLaunchKernelGGL((k_key_groups_huge<V, W>), dim3(KG_HUGE_CAP), dim3(256), 0, st, VA, firstp, newidx, nb, gsum, blk0,
+            hipLaunchKernelGGL((k_key_groups_huge<V, W>), dim3(256), dim3(256), 0, st, VA, firstp, newidx, nb, gsum, blk0,
                                info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf, huge_list);
         tb = 0;
         KSP_HIP(rocprim::exclusive_scan(nullptr, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));

@@ -434,10 +434,12 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict
     __shared__ unsigned long long tkey[HB_SLOTS + 1];
     __shared__ u32 tcnt[HB_SLOTS + 1], toff[HB_SLOTS + 1], trank[HB_SLOTS + 1], tfill[HB_SLOTS + 1];
     __shared__ u32 wpe[NWV], wpk[NWV], s_distinct;
-    if (blockIdx.x >= min(overflow[1], HB_BIG_CAP)) return;
-    const u32 b = big_list[blockIdx.x];
-    const u32 b0 = bstart[b], size = bstart[b + 1] - b0;
+    const u32 n_big = min(overflow[1], HB_BIG_CAP);
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (u32 q = blockIdx.x; q < n_big; q += gridDim.x) {   // (a few workgroups walk the list: it is empty for most inputs)
+    const u32 b = big_list[q];
+    const u32 b0 = bstart[b], size = bstart[b + 1] - b0;
+    __syncthreads();   // (the table of the previous bucket is no longer read)
     for (u32 i = tid; i <= HB_SLOTS; i += NT) { tkey[i] = EMPTY; tcnt[i] = 0; tfill[i] = 0; }
     if (tid == 0) s_distinct = 0;
     __syncthreads();
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict
     __syncthreads();
     if (s_distinct > HB_BIG_DISTINCT) {   // too many distinct keys for the table: the sort path
         if (tid == 0) *overflow = 1;
-        return;
+        continue;
     }
     // exclusive scan over the slots: kept entries, kept keys
     constexpr u32 PER = (HB_SLOTS + 1 + NT - 1) / NT;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict
     for (u32 w = 0; w < NWV; ++w) { if (w < (u32)wv) { re += wpe[w]; rk += wpk[w]; } te += wpe[w]; tk += wpk[w]; }
     if (PART == 0) {
         if (tid == 0) bsum[b] = (u64)te | ((u64)tk << 32);
-        return;
+        continue;
     }
     for (u32 j = 0; j < PER; ++j) {
         const u32 sl = tid * PER + j;
@@ -500,6 +502,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict
             rank2[p] = r;
             if (fill == 0) first[r] = p;
         }
+    }
     }
 }
 
@@ -778,10 +781,12 @@ __global__ __launch_bounds__(256) void k_key_groups_huge(const V* __restrict__ v
                                                          const u32* __restrict__ ovf, const u32* __restrict__ huge_list) {
     __shared__ u32 tab[KG_HUGE_NB * 4];
     __shared__ u32 s_part[4], s_g0big;
-    if (blockIdx.x >= min(ovf[1], KG_HUGE_CAP)) return;
-    const u32 r = huge_list[blockIdx.x];
-    const u32 fa = first[r], c = first[r + 1] - fa;
+    const u32 n_huge = min(ovf[1], KG_HUGE_CAP);
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (u32 q = blockIdx.x; q < n_huge; q += gridDim.x) {   // (a few workgroups walk the list: it is empty for most inputs)
+    const u32 r = huge_list[q];
+    const u32 fa = first[r], c = first[r + 1] - fa;
+    __syncthreads();   // (the table of the previous key is no longer read)
     for (u32 i = tid; i < nb * 4; i += 256) tab[i] = 0;
     if (tid == 0) s_g0big = 0;
     __syncthreads();
@@ -840,6 +845,7 @@ __global__ __launch_bounds__(256) void k_key_groups_huge(const V* __restrict__ v
         ++j;
     }
     if (tid == 255) gsum[r] = (u64)j | ((u64)bigs << 32);   // (the last thread's running totals are the key's totals)
+    }
 }
 // the parked records to their places in rank order (goff = exclusive scan of gsum): block, rank << 32 |
 // posting word, rank; masks to their final index.  With `work` set (at most KG_WORK blocks) the kernel also
