@@ -198,6 +198,28 @@ def test_keys_with_thousands_of_holders(oracle_lib):
     _check(synth.from_runs(runs), oracle_lib)
 
 
+def test_weighted_keys_with_thousands_of_holders():
+    """Colour weights through the big-bucket / huge-key kernels and the wave-per-key walk: two keys held by all
+    2 300 sources (weights 7 and 1 000), one held by the first 100 (weight 50), private keys besides."""
+    rng = np.random.default_rng(44)
+    n = 2300
+    a_key, b_key, c_key = np.uint64(3) << np.uint64(50), np.uint64(5) << np.uint64(49), np.uint64(9) << np.uint64(48)
+    keys, wts, offs = [], [], [0]
+    for s_ in range(n):
+        own = np.unique(rng.integers(0, 1 << 45, size=5, dtype=np.uint64))
+        k = np.concatenate([own, [c_key] if s_ < 100 else [], [b_key, a_key]]).astype(np.uint64)
+        w = np.concatenate([np.full(own.size, 3), [50] if s_ < 100 else [], [1000, 7]]).astype(np.uint32)
+        order = np.argsort(k)
+        keys.append(k[order]); wts.append(w[order]); offs.append(offs[-1] + k.size)
+    keys = np.concatenate(keys); wts = np.concatenate(wts); offs = np.array(offs, dtype=np.uint64)
+    edges, _ = engine.pairwise_host(keys, offs, wts)
+    assert len(edges) == n * (n - 1) // 2
+    s1, s2, sh = edges["source_1"].astype(np.int64), edges["source_2"].astype(np.int64), edges["shared"].astype(np.int64)
+    assert (s1 < s2).all()
+    want = 1007 + 50 * ((s1 < 100) & (s2 < 100))
+    assert (sh == want).all()
+
+
 def test_active_tiles_are_exactly_the_block_pairs_that_share_a_key(oracle_lib, monkeypatch):
     """In the caller's order (KSP_REORDER=0) the blocks are source // 128, so the work list can be checked
     against the sketches: a tile is active iff its two blocks share a key (diagonal: a key with two holders
