@@ -342,8 +342,8 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
         const u32 bn = b + gridDim.x;
         u32 n0 = nw, nraw = 0;          // bounds of the next bucket
         if (bn < nbuckets) { n0 = bstart[bn]; nraw = bstart[bn + 1] - n0; }
-        // the table is as large as the bucket needs (load at most 3/4 even if no two keys are equal)
-        const u32 slots = size <= 384 ? 512u : size <= 768 ? 1024u : size <= 1536 ? 2048u : HB_SLOTS;
+        // the table is as large as the bucket needs (load at most 13/16 even if no two keys are equal)
+        const u32 slots = size <= 416 ? 512u : size <= 832 ? 1024u : size <= 1664 ? 2048u : HB_SLOTS;
         for (u32 i = tid; i <= slots; i += NT) tkey[i] = EMPTY;
         for (u32 i = tid; i <= slots / 2; i += NT) tcnt2[i] = 0;
         __syncthreads();
