@@ -232,10 +232,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if (phase == 3) {
         m = n;
         e->n_kept = m;
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, iota, N);
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, N);
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, newidx, N);
-        hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, label, N);
+        hipLaunchKernelGGL(k_iota4, dim3(grid_for(N, bs)), dim3(bs), 0, st, iota, order, newidx, label, N);
         KSP_HIP(hipMemsetAsync(e->blk_max.p, 0, ((size_t)nb + 1) * 4, st));
         KSP_HIP(hipMemsetAsync(sbound, 0, (size_t)N * 4, st));
         const u32 nk = e->post_nkeys;
@@ -270,10 +267,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if (W || e->nparts == 1)   // (weighted slices still need the per-source weight sums of all entries)
         hipLaunchKernelGGL((k_tag<V, W>), dim3(N), dim3(256), 0, st, d_off, d_w, VA, sbound);
     if (!W) hipLaunchKernelGGL(k_src_size, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_off, sbound, N);
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, iota, N);
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, N);    // identity until the labels are known
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, newidx, N);
-    hipLaunchKernelGGL(k_iota, dim3(grid_for(N, bs)), dim3(bs), 0, st, label, N);
+    hipLaunchKernelGGL(k_iota4, dim3(grid_for(N, bs)), dim3(bs), 0, st, iota, order, newidx, label, N);   // (order, newidx: identity until the labels are known)
     KSP_HIP(hipMemsetAsync(e->blk_max.p, 0, ((size_t)nb + 1) * 4, st));
     if (!reorder) hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
     // slice mode (multi-GPU build): keep only the entries of this part's key range — one contiguous
@@ -378,9 +372,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                            bbase, bsum, nbuckets, VA, rank1, first, scal);
         hipLaunchKernelGGL((k_bucket_big<V, 1>), dim3(128), dim3(HB_THREADS), 0, st, KA, VB, bstart, big_list, d_hovf,
                            bsum, bbase, VA, rank1, first);
-        KSP_HIP(hipMemcpyAsync(e->h_scal + 2, scal + 2, 8, hipMemcpyDeviceToHost, st));
-        KSP_HIP(hipMemcpyAsync(e->h_scal + 6, scal + 6, 8, hipMemcpyDeviceToHost, st));
-        KSP_HIP(hipMemcpyAsync(e->h_scal + 9, scal + 9, 8, hipMemcpyDeviceToHost, st));
+        KSP_HIP(hipMemcpyAsync(e->h_scal + 2, scal + 2, 64, hipMemcpyDeviceToHost, st));   // [2] keys, [6] entries, [9] overflow (one copy)
         KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
         if ((u32)e->h_scal[9]) {   // a bucket did not fit (skewed keys): this engine sorts from now on
             e->hash_off = true;
@@ -416,8 +408,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         if ((rc = e->tmp.ensure(tb))) return rc;
         KSP_HIP(rocprim::inclusive_scan(e->tmp.p, tb, pf, out, nw, rocprim::plus<u64>(), st));
     }
-    KSP_HIP(hipMemcpyAsync(e->h_scal + 2, scal + 2, 8, hipMemcpyDeviceToHost, st));
-    KSP_HIP(hipMemcpyAsync(e->h_scal + 6, scal + 6, 8, hipMemcpyDeviceToHost, st));
+    KSP_HIP(hipMemcpyAsync(e->h_scal + 2, scal + 2, 40, hipMemcpyDeviceToHost, st));   // [2] keys ... [6] entries (one copy)
     KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
     }
     m = e->h_scal[6];
@@ -475,8 +466,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
         hipLaunchKernelGGL(k_group_totals, dim3(1), dim3(64), 0, st, gsum, goff, scal, U);
         // the number of groups sizes everything after (one 8-byte read-back pays for itself)
-        KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 8, hipMemcpyDeviceToHost, st));
-        KSP_HIP(hipMemcpyAsync(e->h_scal + 11, scal + 11, 8, hipMemcpyDeviceToHost, st));
+        KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 88, hipMemcpyDeviceToHost, st));   // [1] groups ... [11] overflow (one copy)
         KSP_HIP(hipStreamSynchronize(st));
         if ((u32)e->h_scal[11]) {
             e->key_groups_off = true;   // a key with thousands of holders: this engine sorts by block from now on

@@ -58,6 +58,11 @@ __global__ void k_iota(u32* __restrict__ p, u32 n) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = i;
 }
+// the four identity maps of a build in one launch (iota, source order, new index, label)
+__global__ void k_iota4(u32* __restrict__ p0, u32* __restrict__ p1, u32* __restrict__ p2, u32* __restrict__ p3, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { p0[i] = i; p1[i] = i; p2[i] = i; p3[i] = i; }
+}
 __device__ inline u32 src_of_tag(u32 t) { return (t >> 8) * TB + (t & 0xFFu); }
 template <class V>
 __global__ void k_label(const V* __restrict__ vals, const u32* __restrict__ first, u32* __restrict__ label,
