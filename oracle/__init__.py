@@ -158,7 +158,8 @@ def accumulate_mem(color_off, sources, color_w, user_threads: int = 1, want_edge
     nu = ctypes.c_uint64(0)
     if want_edges:
         m = np.diff(color_off.astype(np.int64))
-        cap = int(max(1, (m * (m - 1) // 2).sum()))
+        top = int(sources.max()) + 1 if sources.size else 1      # (no more pairs than C(#ids, 2) either)
+        cap = int(max(1, min((m * (m - 1) // 2).sum(), top * (top - 1) // 2)))
         out = np.zeros(cap, dtype=EDGE_DTYPE)
         outp = out.ctypes.data_as(ctypes.POINTER(Edge))
     else:
