@@ -4,27 +4,41 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of synthetic sketches that already
-sit in HBM as sorted uint64 runs:
-    stage 1  build_blocks  (prune singletons, rank-encode, merge the runs of every 128-source block;
-                            N > 1: per-rank hash-range slices + all-gather + assemble)
+One "step" = one pass of the hot path (what src/pairwise.cpp:194-237 does on the CPU) over one batch of
+synthetic sketches that already sit in HBM as sorted uint64 runs:
+    stage 1  build_blocks  (partition by key, group equal keys, prune singletons, rank-encode, order the sources,
+                            one posting list per 128-source block; N > 1: per-rank hash-range slices + all-gather)
     stage 2  join          (LDS-tiled intersection of this rank's tile range -> edges in HBM)
     gather   RCCL point-to-point gather of the edge lists to rank 0 (N > 1 only)
     D2H      rank 0 copies the edges to pinned host memory (the hand-over to the TSV writer)
+Nothing about the data is handed to the engine from the host side (no key range, no cached layout): tile
+cuts and buffer sizes are taken from each step's own build.
 
-Workload: BASELINE.json configs[1] ("10k sourmash signatures, scaled=1000, k=31" ->
-synthetic C2: 10 000 sketches, n ~ N(5000, 1500), hashes < 2^64/1000).  N > 1 is WEAK
-scaling: the source count grows as 10 000 * sqrt(N) so that every GPU keeps the pair count
-of the 1-GPU job; every rank holds the full sketch set; stage 1 is sharded by hash range
-(rank r builds the block-list slices of its 1/N share of the keys; the slices are exchanged
-with one RCCL all-gather), tiles are sharded, and the edges are gathered to rank 0.
+Workload: BASELINE.json configs[1] ("10k sourmash signatures, scaled=1000, k=31" -> synthetic C2: 10 000
+sketches, n ~ N(5000, 1500), hashes < 2^64/1000).  N > 1, default: WEAK scaling — the source count grows as
+10 000 * sqrt(N) so that every GPU keeps the pair count of the 1-GPU job.  `--scaling strong --config C3` is
+BASELINE.json configs[2] ("100k genomes, 1 vs 8 GPU row-block shard"): the same 100 000 sources on N GPUs.
+Every rank holds the full sketch set; stage 1 is sharded by hash range (one RCCL all-gather of the block-list
+slices), tiles are sharded by estimated work, the edges are gathered to rank 0.
 
-value = whole-job source pairs per second = [S(S-1)/2] * K / t, t = max over ranks of the
-wall time of K steps bracketed by barrier + torch.cuda.synchronize().
+value = whole-job source pairs per second = [S(S-1)/2] * K / t, t = max over ranks of the wall time of K
+steps bracketed by barrier + torch.cuda.synchronize().
+
+The JSON line also carries (N = 1):
+  roofline       HBM roofline of the whole step: the bytes the step MUST move (SURVEY 8d "compulsory":
+                 8 * sum(n) read once + 16 bytes per non-zero pair written) / step time / 8 TB/s — a fraction
+                 <= 1 — plus the dominant kernel group and, per kernel group of stage 1 + the join, HIP-event
+                 time, modelled bytes and (when profiles/traffic.json was measured on the same kernels) PMC bytes
+  naive_pairwise the pairwise-merge-equivalent rate A/t (SURVEY 8d's per-pair bytes; exceeds the HBM peak by
+                 design: the engine never reads a sketch once per source pair) — NOT a roofline
+  cpu_baseline   the reference algorithm (oracle port) on the host cores, 1 thread and all cores
+  other_configs  one timed step each of C3 / C4 / C5 at full size (build + join + D2H into pinned memory)
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import math
 import os
@@ -40,52 +54,87 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def algorithmic_bytes(sizes: np.ndarray, n_sources: int, t0: int, t1: int) -> int:
-    """SURVEY §8(d) per-pair figure B(a,b) = 8 (n_a + n_b) + 4, summed over the source pairs
-    of tiles [t0, t1) of the row-major block-pair upper triangle (128-source blocks)."""
-    tb = 128
-    nb = (n_sources + tb - 1) // tb
-    cnt = np.array([min(tb, n_sources - b * tb) for b in range(nb)], dtype=np.int64)
-    tot = np.add.reduceat(sizes.astype(np.int64), np.arange(0, n_sources, tb))
-    sq = None
-    total = 0
-    t = 0
-    for i in range(nb):
-        row = nb - i
-        lo, hi = max(t0, t), min(t1, t + row)
-        if lo < hi:
-            js = np.arange(i + (lo - t), i + (hi - t))
-            for j in js:
-                if j == i:
-                    pairs = cnt[i] * (cnt[i] - 1) // 2
-                    total += 8 * (cnt[i] - 1) * tot[i] + 4 * pairs
-                else:
-                    total += 8 * (cnt[j] * tot[i] + cnt[i] * tot[j]) + 4 * cnt[i] * cnt[j]
-        t += row
-        if t >= t1:
-            break
-    return int(total)
+def kernel_source_hash() -> str:
+    """sha256 over the HIP sources: profiles/traffic.json is only quoted when it was measured on these kernels."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "kspider_amd", "csrc", "*.hip*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def naive_pairwise_bytes(sizes: np.ndarray, n_sources: int) -> int:
+    """SURVEY 8(d) per-pair figure B(a,b) = 8 (n_a + n_b) + 4 summed over all source pairs:
+    A = 8 (N - 1) sum(n) + 4 N (N - 1) / 2."""
+    return int(8 * (n_sources - 1) * int(sizes.sum()) + 4 * (n_sources * (n_sources - 1) // 2))
 
 
 def cpu_baseline(sk, sample_sources: int) -> dict:
-    """Reference algorithm (oracle restatement of src/pairwise.cpp:194-237) on the host cores,
-    on a bounded sample of the same workload.  Reported next to the GPU number, not a target."""
+    """Reference algorithm (oracle restatement of src/pairwise.cpp:194-237) on the host cores, on a bounded
+    sample of the same workload, with user_threads = 1 and = all cores.  A reported baseline."""
     import oracle
     sub = sk.subset(sample_sources)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 64))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     t0 = time.perf_counter()
     co, src, w = oracle.build_colors(sub.keys, sub.offsets)
     t_index = time.perf_counter() - t0
-    secs, n_edges, n_updates, _ = oracle.accumulate_mem(co, src, w, cores, want_edges=False)
     n = sub.n_sources
+    pairs = n * (n - 1) // 2
+    runs = []
+    for threads in sorted({1, max(1, avail)}):
+        secs, n_edges, n_updates, _ = oracle.accumulate_mem(co, src, w, threads, want_edges=False)
+        runs.append({"cores": threads, "secs": secs, "value": pairs / secs})
+    best = max(runs, key=lambda r: r["value"])
     return {
-        "value": (n * (n - 1) // 2) / secs, "unit": "pairs/s", "cores": cores, "kind": "port",
+        "value": best["value"], "unit": "pairs/s", "cores": best["cores"], "kind": "port",
         "sample": f"first {n} of the workload's sources ({int(sub.offsets[-1])} hashes, {len(w)} colours, "
                   f"{n_updates} map updates, {n_edges} non-zero pairs); accumulate region only "
-                  f"(src/pairwise.cpp:200-239 equivalent) {secs:.2f} s; colour index build {t_index:.1f} s not counted",
-        "secs": secs,
+                  f"(src/pairwise.cpp:200-239 equivalent); colour index build {t_index:.1f} s not counted; "
+                  f"host has {avail} usable cores",
+        "secs": best["secs"], "runs": runs,
     }
+
+
+def run_other_config(cfg: str, torch, dev, engine, synth) -> dict:
+    """One timed step of a full-size BASELINE config on this GPU: build + join + D2H of the edges into pinned
+    memory (a first, untimed step sizes the buffers).  No host-side checks inside the timed region — the
+    checks live in tests/test_configs_gpu.py."""
+    t = time.perf_counter()
+    sk = synth.generate(cfg)
+    t_gen = time.perf_counter() - t
+    n = sk.n_sources
+    keys_d = torch.from_numpy(sk.keys.view(np.int64)).to(dev)
+    eng = engine.Engine(dev.index or 0)
+    stream = torch.cuda.current_stream(dev)
+    out = {"config": cfg, "n_sources": n, "hashes": int(sk.offsets[-1]), "pairs": n * (n - 1) // 2,
+           "generate_s": round(t_gen, 1)}
+    edges_d = edges_h = None
+    for timed in (False, True):
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        eng.build_blocks(keys_d.data_ptr(), sk.offsets, stream=stream.cuda_stream)
+        T = eng.num_tiles
+        need = int(min(eng.edge_bound(0, T), 1 << 27)) + 1
+        if edges_d is None or edges_d.shape[0] < need:
+            edges_d = torch.empty((need, 16), dtype=torch.uint8, device=dev)
+        cnt = eng.join(0, T, edges_d.data_ptr(), edges_d.shape[0], stream=stream.cuda_stream)
+        if edges_h is None or edges_h.shape[0] < cnt:
+            edges_h = torch.empty((cnt + cnt // 8 + 1, 16), dtype=torch.uint8).pin_memory()
+            if timed:
+                out["note"] = "the pinned buffer had to grow inside the timed step"
+        edges_h[:cnt].copy_(edges_d[:cnt], non_blocking=True)
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t
+        if timed:
+            st = eng.stats()
+            out.update({"step_ms": 1e3 * wall, "build_ms": st["ms_build"], "join_ms": st["ms_join"],
+                        "d2h_and_host_ms": 1e3 * wall - st["ms_build"] - st["ms_join"], "nonzero_pairs": int(cnt),
+                        "pairs_per_s": out["pairs"] / wall, "active_tiles": int(st["n_active_tiles"]),
+                        "tiles": int(T), "partition_kind": int(st["partition_kind"]),
+                        "compulsory_GBps": (8 * out["hashes"] + 16 * cnt) / wall / 1e9})
+    eng.close()
+    del keys_d, edges_d, edges_h
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -94,8 +143,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C2")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: sources = N(config) * sqrt(gpus); strong: the config's own size on every GPU count")
     ap.add_argument("--n-sources", type=int, default=0, help="override the source count (debug)")
     ap.add_argument("--cpu-sample", type=int, default=10000, help="sources in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--other-configs", default="C3,C4,C5",
+                    help="full-size configs timed once each after the main measurement (N = 1 only; '' = skip)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="extra steps with per-phase events (N = 1; 0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -126,53 +180,61 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     base_n = synth.CONFIGS[args.config]["n"]
-    n_sources = args.n_sources or int(round(base_n * math.sqrt(world)))
+    if args.n_sources:
+        n_sources = args.n_sources
+    elif args.scaling == "weak":
+        n_sources = int(round(base_n * math.sqrt(world)))
+    else:
+        n_sources = base_n
     sk = synth.generate(args.config, n_sources=n_sources)   # identical on every rank (deterministic)
     n = sk.n_sources
     total_pairs = n * (n - 1) // 2
+    n_hashes = int(sk.offsets[-1])
 
     keys_d = torch.from_numpy(sk.keys.view(np.int64)).to(dev)
-    key_bits = max(1, int(sk.keys.max()).bit_length()) if sk.keys.size else 1   # the sketcher knows its hash range
     stream = torch.cuda.current_stream(dev)
     eng = engine.Engine(local_rank)
-    sharded = world > 1 and os.environ.get("KSP_BENCH_REPLICATED_BUILD") != "1"
-    # one untimed build fixes this rank's tile range (equal estimated work per GPU; the data and
-    # therefore the cuts are the same in every step) and sizes the edge buffers
-    if sharded:
-        kdist.build_blocks_sharded(eng, keys_d.data_ptr(), sk.offsets, world, rank, dev, stream=stream.cuda_stream)
-    else:
-        eng.build_blocks(keys_d.data_ptr(), sk.offsets, key_bits=key_bits, stream=stream.cuda_stream)
-    cuts = eng.balanced_cuts(world)
-    t0, t1 = cuts[rank], cuts[rank + 1]
-    cap = int(min(eng.edge_bound(t0, t1), 1 << 27)) + 1
+    sharded = world > 1
     # double-buffered results: the D2H copy of step k runs on its own stream under stage 1 of step k + 1
-    edges_dd = [torch.empty((cap, 16), dtype=torch.uint8, device=dev) for _ in range(2)]
-    host_cap = int(min(eng.edge_bound(0, eng.num_tiles), total_pairs, 1 << 27)) + 1
-    edges_hh = [torch.empty((host_cap, 16), dtype=torch.uint8).pin_memory() for _ in range(2)] if rank == 0 else None
+    edges_dd = [None, None]
+    edges_hh = [None, None]
     copy_stream = torch.cuda.Stream(device=dev)
     copied = [None, None]     # event: the D2H copy out of buffer i has finished
     in_flight = [None, None]  # keeps the gathered device tensor alive until its copy is done
     step_no = [0]
 
-    stats = {"ms_join": 0.0, "ms_build": 0.0, "edges": 0, "stream_bytes": 0, "xchg_bytes": 0}
+    stats = {"ms_join": 0.0, "ms_build": 0.0, "ms_sort": 0.0, "edges": 0, "stream_bytes": 0, "xchg_bytes": 0,
+             "regrown": 0}
 
     def step(record: bool):
-        if sharded:   # stage 1 sharded by hash range + all-gather of the block-list slices
+        # stage 1; every step takes its tile range and buffer sizes from ITS OWN build (the engine's source order,
+        # and with it the tile numbering, differs from build to build)
+        if sharded:   # sharded by hash range + all-gather of the block-list slices: every rank assembles the same lists
             stats["xchg_bytes"] = kdist.build_blocks_sharded(eng, keys_d.data_ptr(), sk.offsets, world, rank, dev,
                                                              stream=stream.cuda_stream)
         else:
-            eng.build_blocks(keys_d.data_ptr(), sk.offsets, key_bits=key_bits, stream=stream.cuda_stream)
+            eng.build_blocks(keys_d.data_ptr(), sk.offsets, stream=stream.cuda_stream)
+        cuts = eng.balanced_cuts(world)
+        t0, t1 = cuts[rank], cuts[rank + 1]
         buf = step_no[0] & 1
         step_no[0] += 1
         if copied[buf] is not None:
             copied[buf].synchronize()       # the copy that last read this buffer pair (two steps ago)
-        edges_d, edges_h = edges_dd[buf], (edges_hh[buf] if rank == 0 else None)
-        cnt = eng.join(t0, t1, edges_d.data_ptr(), cap, stream=stream.cuda_stream)
+        need = int(min(eng.edge_bound(t0, t1), 1 << 27)) + 1
+        if edges_dd[buf] is None or edges_dd[buf].shape[0] < need:
+            edges_dd[buf] = torch.empty((need + need // 8, 16), dtype=torch.uint8, device=dev)
+            stats["regrown"] += 1
+        edges_d = edges_dd[buf]
+        cnt = eng.join(t0, t1, edges_d.data_ptr(), edges_d.shape[0], stream=stream.cuda_stream)
         local = edges_d[:cnt]
         if world > 1 and backend != "nccl":
             local = local.cpu()     # gloo exchanges host tensors (test hook only)
         allv = kdist.gather_edges(local, dst=0) if world > 1 else local
         if rank == 0:
+            if edges_hh[buf] is None or edges_hh[buf].shape[0] < allv.shape[0]:
+                edges_hh[buf] = torch.empty((allv.shape[0] + allv.shape[0] // 8 + 1, 16), dtype=torch.uint8).pin_memory()
+                stats["regrown"] += 1
+            edges_h = edges_hh[buf]
             ready = torch.cuda.Event()
             ready.record(stream)            # (the gather's kernels run on the compute stream)
             with torch.cuda.stream(copy_stream):
@@ -185,13 +247,15 @@ def main():
             st = eng.stats()
             stats["ms_join"] += st["ms_join"]
             stats["ms_build"] += st["ms_build"]
-            stats["ms_sort"] = stats.get("ms_sort", 0.0) + st["ms_sort"]
+            stats["ms_sort"] += st["ms_sort"]
             stats["sort_entries"], stats["sort_bits"] = st["sort_entries"], st["sort_bits"]
+            stats["partition_kind"] = st["partition_kind"]
             stats["stream_bytes"] = st["last_stream_bytes"]
             stats["edges"] = int(allv.shape[0]) if rank == 0 else cnt
+            stats["active_tiles"] = int(st["n_active_tiles"])
             if rank == 0 and os.environ.get("KSP_BENCH_CHECKSUM") == "1":
                 copy_stream.synchronize()
-                ev = edges_h[: allv.shape[0]].numpy().view(engine.EDGE_DTYPE).reshape(-1)
+                ev = edges_hh[buf][: allv.shape[0]].numpy().view(engine.EDGE_DTYPE).reshape(-1)
                 stats["checksum"] = int(ev["shared"].sum()) ^ (int(ev["source_1"].astype(np.int64).sum()) << 20) ^ int(
                     ev["source_2"].astype(np.int64).sum())
         return cnt
@@ -203,8 +267,9 @@ def main():
 
     stats["checksum"] = 0
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 2)):   # (at least two: both buffer pairs get their size before the clock starts)
         step(False)
+    stats["regrown"] = 0
     barrier()
     t_start = time.perf_counter()
     for _ in range(args.steps):
@@ -216,55 +281,95 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    ms_join = stats["ms_join"] / max(1, args.steps)
-    ms_build = stats["ms_build"] / max(1, args.steps)
-    alg_bytes = algorithmic_bytes(sk.sizes, n, t0, t1)       # this rank's launch
-    achieved = alg_bytes / (ms_join * 1e-3) / 1e9 if ms_join > 0 else 0.0
-    stream_gbs = stats["stream_bytes"] / (ms_join * 1e-3) / 1e9 if ms_join > 0 else 0.0
+    steps = max(1, args.steps)
+    ms_step = 1e3 * elapsed / steps
+    ms_join = stats["ms_join"] / steps
+    ms_build = stats["ms_build"] / steps
+    ms_part = stats["ms_sort"] / steps
 
     if rank == 0:
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(prof):
-            try:
-                traffic = json.load(open(prof)).get("k_join_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        E = int(stats["edges"])
+        compulsory = 8 * n_hashes + 16 * E                 # every hash read once, every non-zero pair written once
+        achieved = compulsory / (ms_step * 1e-3) / 1e9 / world
+        # ---- per kernel group: HIP events at the phase starts of a few extra, untimed steps ----------------
+        groups = []
+        tag_b = 2 if n <= 65536 and not os.environ.get("KSP_TAG32") else 4
+        if world == 1 and args.profile_steps > 0:
+            eng.set_profiling(True)
+            acc, joins = {}, 0.0
+            order = []
+            for _ in range(args.profile_steps):
+                step(False)
+                torch.cuda.synchronize(dev)
+                for name, ms in eng.phase_times():
+                    if name not in acc:
+                        order.append(name)
+                    acc[name] = acc.get(name, 0.0) + ms
+                joins += eng.stats()["ms_join"]
+            eng.set_profiling(False)
+            kept = None
+            # bytes each group has to move per step; None where no simple model applies
+            hand = stats.get("partition_kind") == 2
+            model = {
+                "partition": n_hashes * ((8 + 8 + tag_b + 1) + (1 + 8 + tag_b) + (8 + tag_b)) if hand
+                else n_hashes * ((8 + tag_b) * 2 * ((int(stats.get("sort_bits", 16)) + 7) // 8) + 8),
+                "bucket grouping": n_hashes * (8 + 4 + 4 + tag_b),
+                "tags + source sizes": n_hashes * tag_b,
+            }
+            traffic = {}
+            prof = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(prof):
+                try:
+                    tj = json.load(open(prof))
+                    if tj.get("kernel_source_hash") == kernel_source_hash():
+                        traffic = tj.get("groups", {})
+                except Exception:
+                    traffic = {}
+            for name in order + ["join"]:
+                ms = (acc[name] if name != "join" else joins) / args.profile_steps
+                mb = model.get(name) if name != "join" else stats["stream_bytes"] + 16 * E
+                cb = traffic.get(name, {}).get("hbm_bytes_per_step")
+                groups.append({"group": name, "ms": ms, "model_bytes": mb,
+                               "model_GBps": (mb / (ms * 1e-3) / 1e9) if (mb and ms > 0) else None,
+                               "counter_bytes": cb,
+                               "frac_of_hbm": ((cb or mb) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ((cb or mb) and ms > 0) else None})
+        dominant = max(groups, key=lambda g: g["ms"]) if groups else {"group": "stage 1", "ms": ms_build}
+        step_traffic = None
+        if groups and all(g["counter_bytes"] is not None for g in groups):
+            step_traffic = int(sum(g["counter_bytes"] for g in groups))
+        naive = naive_pairwise_bytes(sk.sizes, n)
         out = {
             "metric": "sketch-pairs/sec (NxN containment)", "value": total_pairs * args.steps / elapsed,
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u64 keys -> u32 ranks, u32 counters", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: {args.config} synthetic sourmash-like sketches "
-                                   f"(scaled=1000 hash range), {n} sources, {int(sk.offsets[-1])} hashes; "
-                                   f"weak scaling: sources = {base_n}*sqrt(n_gpus)",
-                       "n_sources": n, "pairs": total_pairs, "nonzero_pairs": stats["edges"],
+            "config": {"workload": (f"BASELINE configs[{synth.CONFIGS[args.config]['idx'] - 1}]: {args.config} synthetic "
+                                    f"sketches, {n} sources, {n_hashes} hashes; "
+                                    + (f"weak scaling: sources = {base_n}*sqrt(n_gpus)" if args.scaling == "weak"
+                                       else "strong scaling: the same sources on every GPU count")),
+                       "n_sources": n, "pairs": total_pairs, "nonzero_pairs": E,
                        "checksum": stats["checksum"],
-                       "tiles": int(eng.num_tiles), "active_tiles": int(eng.stats()["n_active_tiles"]),
-                       "parallelism": (f"tile-range shard x{world}; stage 1 "
+                       "tiles": int(eng.num_tiles), "active_tiles": stats.get("active_tiles"),
+                       "key_range": "found on the device (no key_bits hint)",
+                       "buffers_regrown_in_timed_region": stats["regrown"],
+                       "parallelism": (f"tile-range shard x{world} by estimated work, cuts from every step's own build; stage 1 "
                                        + ("sharded by hash range + RCCL all-gather of the block-list slices "
                                           f"({stats['xchg_bytes'] / 1e6:.0f} MB received per rank)" if sharded
-                                          else "replicated") + "; RCCL p2p gather of the edges to rank 0")},
+                                          else "on the one GPU") + "; RCCL p2p gather of the edges to rank 0")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ksp::k_join", "ms_per_launch": ms_join,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "algorithmic bytes = SURVEY 8(d): sum over the launch's source pairs of "
-                                 "8(n_a+n_b)+4; the kernel streams block-merged rank lists instead, "
-                                 "see stream_model"},
-            "stage1_sort": (lambda ms, n_e, bits, tb=(2 if n <= 65536 and not os.environ.get("KSP_TAG32") else 4): {
-                "kernel": "rocprim radix_sort_onesweep (stage 1 partitions the entries by their top key bits before the LDS hash grouping: the largest kernel group of the step)",
-                "entries": n_e, "key_bits": bits, "passes": (bits + 7) // 8, "ms": ms,
-                "bytes": n_e * (8 + tb) * 2 * ((bits + 7) // 8),
-                "GBps": (n_e * (8 + tb) * 2 * ((bits + 7) // 8)) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
-                "frac_of_hbm_peak": (n_e * (8 + tb) * 2 * ((bits + 7) // 8)) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else 0.0,
-                "note": f"8-byte key + {tb}-byte tag read and written once per 8-bit pass (histogram pass not counted)"})(
-                    stats.get("ms_sort", 0.0) / max(1, args.steps), int(stats.get("sort_entries", 0)), int(stats.get("sort_bits", 0))),
-            "stream_model": {"bytes_per_launch": stats["stream_bytes"], "GBps": stream_gbs,
-                             "frac_of_peak": stream_gbs / HBM_PEAK_GBS,
-                             "note": "4-byte ranks of both block lists per tile (what k_join must read)"},
-            "stage_ms": {"build_blocks": ms_build, "join": ms_join,
-                         "other (gather, D2H, sync)": 1e3 * elapsed / args.steps - ms_build - ms_join},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": step_traffic,
+                         "kernel": f"whole step; dominant kernel group: {dominant['group']} ({dominant['ms']:.3f} ms)",
+                         "bytes_per_step": compulsory,
+                         "note": "compulsory traffic of one step (SURVEY 8d): 8 B x every hash read once + 16 B x every "
+                                 "non-zero pair written once, / ms_per_step / n_gpus; `traffic` = PMC bytes per step summed "
+                                 "over the kernel groups when profiles/traffic.json matches these kernels",
+                         "groups": groups},
+            "naive_pairwise": {"bytes_per_step": naive, "GBps": naive / (ms_step * 1e-3) / 1e9,
+                               "x_hbm_peak": naive / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world,
+                               "note": "SURVEY 8(d) per-pair bytes 8(n_a+n_b)+4 over all pairs / step time: what a "
+                                       "pair-by-pair merge would have to stream; not a roofline of this engine"},
+            "stage_ms": {"build_blocks": ms_build, "of which partition": ms_part, "join": ms_join,
+                         "other (gather, D2H, sync, host)": ms_step - ms_build - ms_join},
         }
         if world == 1 and args.cpu_sample > 0:
             try:
@@ -272,6 +377,15 @@ def main():
             except Exception as ex:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {ex}"}
+        if world == 1 and args.other_configs and not args.n_sources:
+            del keys_d
+            others = []
+            for cfg in [c for c in args.other_configs.split(",") if c and c != args.config]:
+                try:
+                    others.append(run_other_config(cfg, torch, dev, engine, synth))
+                except Exception as ex:
+                    others.append({"config": cfg, "error": str(ex)})
+            out["other_configs"] = others
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

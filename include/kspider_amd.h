@@ -57,6 +57,9 @@ typedef struct ksp_stats {
                                    8-byte key + 4/8-byte tag read and written once per 8-bit pass)      */
     float ms_sort;              /* its HIP-event time (all passes + histogram)                        */
     int sort_bits;              /* key bits it sorted on                                              */
+    int partition_kind;         /* how the last build brought equal keys together: 0 nothing to do / postings
+                                   input, 1 rocPRIM radix partition or sort, 2 the hand-written two-level
+                                   partition (partition_kernels.hip.h)                                   */
 } ksp_stats;
 
 const char* ksp_last_error(void);
@@ -97,6 +100,12 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
                     uint64_t* h_count, void* stream);
 
 int ksp_engine_get_stats(const ksp_engine* e, ksp_stats* out);
+/* Per-phase HIP-event times of stage 1 (the reference's own phase timers, src/pairwise.cpp:131-133,155,181,
+ * 239, print wall-clock seconds per phase; this is their device-side counterpart).  set_profiling(1) makes
+ * every later build record one event per phase start; phase_times returns the phases of the last build:
+ * names[i] (static strings) and ms[i], at most cap of them; the return value is the count.               */
+int ksp_engine_set_profiling(ksp_engine* e, int on);
+int ksp_engine_phase_times(const ksp_engine* e, const char** names, float* ms, int cap);
 
 /* Stage 1 from an inverted index instead of sketches: key k is held by the sources
  * d_sources[h_key_off[k] .. h_key_off[k+1]) (dense source indices, distinct inside a key, at least two per

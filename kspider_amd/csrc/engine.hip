@@ -67,6 +67,7 @@ constexpr u32 BIG = 0xE0000000u;      // posting word: more than INLINE_MAX sour
 constexpr u32 INLINE_MAX = 4;         // sources whose 7-bit ids fit into the posting word
 
 #include "stage1_kernels.hip.h"
+#include "partition_kernels.hip.h"
 #include "join_kernels.hip.h"
 
 // ------------------------------------------------------------------------------------
@@ -109,6 +110,16 @@ struct ksp_engine {
     bool use_cells = true;        // rank-aligned cell join (KSP_JOIN=window selects the sliding-window merge)
     bool full_sort = false;       // keys defeat the 32-bit prefix sort: use all bits
     bool hash_off = false;        // keys defeat the bucket grouping (a bucket overflowed): use the sort path
+    bool part_off = false;        // the hand-written partition gave up on these keys (page tables full): rocPRIM partition
+    u32 part_min = 4096;          // entries from which the hand-written partition is used (KSP_PART_MIN)
+    ksp::Buf PK, PT, PD, parena;  // level-1 pages of the partition: keys, tags, digit bytes; pools, cursors, page tables
+    // phase timers (ksp_engine_set_profiling): events at the phase starts of the last build / join
+    bool profiling = false;
+    static constexpr int kMaxPhase = 24;
+    hipEvent_t ph_ev[kMaxPhase] = {};
+    const char* ph_name[kMaxPhase] = {};
+    int ph_n = 0;
+    float ph_ms[kMaxPhase] = {};
     u32 hb_slots = 0;             // workgroups of k_bucket_group the device holds at once
     bool key_groups_off = false;  // a key has too many holders for the key-by-key list build: sort the entries by block
     bool have_rank_pairs = false; // gp holds (block, rank) of every list word in rank order (key-by-key build)
@@ -139,6 +150,7 @@ struct ksp_engine {
     u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
     u64 sort_entries = 0;                    // entries / key bits of the last global radix sort (stats)
     int sort_bits = 0;
+    int part_kind = 0;                       // 1 rocPRIM, 2 hand-written partition (stats)
     u64 h_scal_words = 0, h_scal_keys = 0;   // list words / distinct shared keys of the lists being finished
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // build, join, first radix sort
     ksp_stats st{};
@@ -147,6 +159,20 @@ struct ksp_engine {
 namespace ksp {
 
 static inline unsigned grid_for(u64 n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// start of a phase of stage 1 / the join (only with ksp_engine_set_profiling: an event per phase start)
+static inline void phase_mark(ksp_engine* e, hipStream_t st, const char* name) {
+    if (!e->profiling || e->ph_n >= ksp_engine::kMaxPhase) return;
+    (void)hipEventRecord(e->ph_ev[e->ph_n], st);
+    e->ph_name[e->ph_n++] = name;
+}
+// durations of the phases marked since the last reset; `end`: event behind the last phase (stream is idle)
+static inline void phase_close(ksp_engine* e, hipEvent_t end) {
+    for (int i = 0; i < e->ph_n; ++i) {
+        e->ph_ms[i] = 0;
+        (void)hipEventElapsedTime(&e->ph_ms[i], e->ph_ev[i], i + 1 < e->ph_n ? e->ph_ev[i + 1] : end);
+    }
+}
 
 // The label pass looks at one key in (result + 1): ~64 sampled shared keys per source say as much about a
 // source's relatives as all of them.  "Per source" is the small end of the size distribution (the 10th
@@ -250,8 +276,25 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         }
     } else if (phase != 2) {
 
+    // the hand-written partition (partition_kernels.hip.h) finds the key range on the device and makes the
+    // source tags itself: no read-back, no tagging pass.  Unweighted whole builds whose bucket count fits
+    // its two levels; everything else (weighted sketches, key-range slices, > 2^16 buckets) takes the
+    // rocPRIM partition below.
+    int pb_hand = 0;
+    if (!W && phase == 0 && e->nparts == 1 && !e->hash_off && !e->full_sort && !e->part_off && n >= e->part_min) {
+        pb_hand = 1;
+        while ((n >> pb_hand) > HB_MEAN) ++pb_hand;
+        if (pb_hand > 16) pb_hand = 0;
+    }
+    const bool hand = pb_hand > 0;
+    KSP_HIP(hipMemsetAsync(scal + 4, 0, 8 * 11, st));   // [4] .. [14]: overflow words, counters of the partition
+    if (hand) {
+        phase_mark(e, st, "key range + source sizes");
+        KSP_HIP(hipMemsetAsync(scal, 0, 8, st));
+        hipLaunchKernelGGL(k_max_last, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_keys, d_off, (unsigned long long*)scal, N);
+    }
     // key range (one 8-byte D2H, unless the caller passed key_bits)
-    if (e->key_bits <= 0) {
+    if (!hand && e->key_bits <= 0) {
         KSP_HIP(hipMemsetAsync(scal, 0, 8, st));
         hipLaunchKernelGGL(k_max_last, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_keys, d_off, (unsigned long long*)scal, N);
         KSP_HIP(hipMemcpyAsync(e->h_scal, scal, 8, hipMemcpyDeviceToHost, st));
@@ -264,7 +307,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         e->key_bits = bits;
     }
     const int kbits = e->key_bits;
-    if (W || e->nparts == 1)   // (weighted slices still need the per-source weight sums of all entries)
+    if (!hand) phase_mark(e, st, "tags + source sizes");
+    if ((W || e->nparts == 1) && !hand)   // (weighted slices still need the per-source weight sums of all entries)
         hipLaunchKernelGGL((k_tag<V, W>), dim3(N), dim3(256), 0, st, d_off, d_w, VA, sbound);
     if (!W) hipLaunchKernelGGL(k_src_size, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_off, sbound, N);
     hipLaunchKernelGGL(k_iota4, dim3(grid_for(N, bs)), dim3(bs), 0, st, iota, order, newidx, label, N);   // (order, newidx: identity until the labels are known)
@@ -326,7 +370,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     //  which compare whole keys; folding the two halves of the key range keeps the buckets even)
     if (topbit > 63) topbit = 63;
     int pb = 0;
-    if ((phase == 0 || phase == 1) && !e->hash_off && !e->full_sort && nw >= 4096u) {
+    if (hand) pb = pb_hand;
+    else if ((phase == 0 || phase == 1) && !e->hash_off && !e->full_sort && nw >= 4096u) {
         pb = 1;
         while ((nw >> pb) > HB_MEAN) ++pb;
         if (pb > topbit) pb = 0;   // (few distinct keys, many holders each: the sort path)
@@ -336,23 +381,60 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if (pb) {
         const int shiftb = topbit - pb;
         const u32 nbuckets = 1u << pb;
-        KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, KA, tags_in, VB, nw, shiftb, topbit, st));
-        if ((rc = e->tmp.ensure(tb))) return rc;
-        KSP_HIP(hipEventRecord(e->ev[4], st));
-        KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, keys_in, KA, tags_in, VB, nw, shiftb, topbit, st));
-        KSP_HIP(hipEventRecord(e->ev[5], st));
-        e->sort_entries = nw;
-        e->sort_bits = pb;
         // KB is free until the grouping scans: per-entry records, then the bucket tables
         u32* rec = (u32*)e->KB.p;
         u64* bsum = (u64*)e->KB.p + (nw / 2 + 1);
         u64* bbase = bsum + nbuckets;
         u32* bstart = (u32*)(bbase + nbuckets);   // nbuckets + 1
         u32* d_hovf = (u32*)(scal + 9);
+        if (hand) {
+            // two-level partition by bucket = floor(key * nbuckets / (max key + 1)): d_keys -> pages -> KA, VB, bstart
+            const int pb1 = std::min(pb, 8), pb2 = pb - pb1;
+            const u32 nb1 = 1u << pb1, lists = nb1 * P1_R;
+            const u32 ptw = (u32)std::min<u64>(P1_PTW_MAX, 16 * (((nw / lists) >> P1_PLOG) + 1) + 16);
+            const u64 per_r = nw / P1_R;
+            const u32 pool_r = (u32)((per_r >> P1_PLOG) + (per_r >> (P1_PLOG + 3)) + nb1 + 8);   // pages per sub-list class
+            const size_t pages = (size_t)pool_r * P1_R;
+            if ((rc = e->PK.ensure(pages * P1_PAGE * 8))) return rc;
+            if ((rc = e->PT.ensure(pages * P1_PAGE * sizeof(V)))) return rc;
+            if ((rc = e->PD.ensure(pages * P1_PAGE))) return rc;
+            // arena: pools (one line each), cursors (one line each), page tables | list lengths, bucket starts
+            const size_t zero_words = (size_t)P1_R * P1_LINE + (size_t)lists * P1_LINE + (size_t)lists * ptw;
+            if ((rc = e->parena.ensure((zero_words + lists + nb1 + 2) * 4))) return rc;
+            u32* pools = e->parena.as<u32>();
+            u32* cursors = pools + (size_t)P1_R * P1_LINE;
+            u32* ptab = cursors + (size_t)lists * P1_LINE;
+            u32* lens = ptab + (size_t)lists * ptw;
+            u32* btot = lens + lists;
+            phase_mark(e, st, "partition");
+            KSP_HIP(hipEventRecord(e->ev[4], st));
+            KSP_HIP(hipMemsetAsync(pools, 0, zero_words * 4, st));
+            hipLaunchKernelGGL(k_part_prep, dim3(1), dim3(64), 0, st, scal, nbuckets);
+            hipLaunchKernelGGL((k_part1<V>), dim3(grid_for(nw, P1_CH)), dim3(P1_THREADS), 0, st, d_keys, d_off, N, (u32)nw,
+                               scal, pb2, nbuckets - 1, ptw, pools, cursors, ptab, pool_r, e->PK.as<u64>(), e->PT.as<V>(),
+                               e->PD.as<u8>());
+            hipLaunchKernelGGL(k_part_totals, dim3(1), dim3(256), 0, st, cursors, scal, nb1, ptw, (u32)nw, lens, btot);
+            hipLaunchKernelGGL((k_part2<V>), dim3(nb1), dim3(P2_THREADS), 0, st, scal, lens, btot, ptab, ptw, pb2,
+                               nbuckets - 1, e->PK.as<u64>(), e->PT.as<V>(), e->PD.as<u8>(), KA, VB, bstart, nb1);
+            KSP_HIP(hipEventRecord(e->ev[5], st));
+            phase_mark(e, st, "bucket grouping");
+            KSP_HIP(hipMemsetAsync(bsum, 0, (size_t)nbuckets * 8, st));
+        } else {
+        phase_mark(e, st, "partition");
+        KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, KA, tags_in, VB, nw, shiftb, topbit, st));
+        if ((rc = e->tmp.ensure(tb))) return rc;
+        KSP_HIP(hipEventRecord(e->ev[4], st));
+        KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, keys_in, KA, tags_in, VB, nw, shiftb, topbit, st));
+        KSP_HIP(hipEventRecord(e->ev[5], st));
+        phase_mark(e, st, "bucket grouping");
         KSP_HIP(hipMemsetAsync(d_hovf, 0, 8, st));
         KSP_HIP(hipMemsetAsync(bsum, 0, (size_t)nbuckets * 8, st));
         hipLaunchKernelGGL(k_bucket_bounds, dim3(grid_for((u64)nbuckets + 1, bs)), dim3(bs), 0, st, KA, nw, shiftb, nbuckets,
                            bstart);
+        }
+        e->sort_entries = nw;
+        e->sort_bits = pb;
+        e->part_kind = hand ? 2 : 1;
         if (!e->hb_slots) {   // persistent workgroups: as many as fit on the device at once
             int per_cu = 0, cus = 0;
             KSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bucket_group, HB_THREADS, 0));
@@ -372,8 +454,19 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                            bbase, bsum, nbuckets, VA, rank1, first, scal);
         hipLaunchKernelGGL((k_bucket_big<V, 1>), dim3(128), dim3(HB_THREADS), 0, st, KA, VB, bstart, big_list, d_hovf,
                            bsum, bbase, VA, rank1, first);
-        KSP_HIP(hipMemcpyAsync(e->h_scal + 2, scal + 2, 64, hipMemcpyDeviceToHost, st));   // [2] keys, [6] entries, [9] overflow (one copy)
+        KSP_HIP(hipMemcpyAsync(e->h_scal, scal, 120, hipMemcpyDeviceToHost, st));   // [0] max key, [2] keys, [6] entries, [9] / [14] overflow (one copy)
         KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
+        if (hand) {
+            if ((u32)e->h_scal[PC_OVF]) {   // the page tables could not hold these keys: the library partition from now on
+                e->part_off = true;
+                return build_impl<V>(e, d_keys, d_w, st, phase);
+            }
+            e->max_key = e->h_scal[0];
+            e->have_max_key = true;
+            int bits = 1;
+            while (bits < 64 && (e->max_key >> bits)) ++bits;
+            e->key_bits = bits;
+        }
         if ((u32)e->h_scal[9]) {   // a bucket did not fit (skewed keys): this engine sorts from now on
             e->hash_off = true;
             return build_impl<V>(e, d_keys, d_w, st, phase);
@@ -386,6 +479,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     KSP_HIP(hipEventRecord(e->ev[5], st));
     e->sort_entries = nw;
     e->sort_bits = kbits - shift;
+    e->part_kind = 1;
     if (shift > 0) {
         // KB is free until the rank scan: use it for the work list of mixed runs
         u32* fixlist = (u32*)e->KB.p;
@@ -416,6 +510,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if (m == 0 && phase == 0) return KSP_OK;   // no key is shared by two sources: no pair at all
     if (reorder && m) {
         // label = smallest source id among the holders of a source's shared keys
+        phase_mark(e, st, "source labels + order");
         run_label(first, (u32)e->h_scal[2], m);
     }
     if (phase == 1) return KSP_OK;
@@ -451,6 +546,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         u32* wkey = W ? (u32*)VB : nullptr;   // (VB: the partitioned tags are dead)
         u32* d_kovf = (u32*)(scal + 11);
         const u32 chunks = (u32)((m + KG_CHUNK - 1) / KG_CHUNK);
+        phase_mark(e, st, "key groups");
         KSP_HIP(hipMemsetAsync(d_kovf, 0, 8, st));
         KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input — are visited by no chunk)
         hipLaunchKernelGGL((k_key_groups<V, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, rank1, firstp, newidx, (u32)m, U,
@@ -477,6 +573,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             u32 *rec_blk = (u32*)(rec_val + (K + 4)), *rec_rank = rec_blk + (K + 4), *sblk = rec_rank + (K + 4);
             u64* sval = (u64*)KA;             // (the per-key counts and offsets are dead once the records are packed)
             // (the diagonal work and holder sums of the join's schedule come with the move when the blocks fit its LDS table)
+            phase_mark(e, st, "block lists");
             unsigned long long* work = nullptr;
             if (nb <= KG_WORK && phase != 2) {
                 if ((rc = e->dwork.ensure(((size_t)nb + 2) * 8))) return rc;
@@ -586,6 +683,7 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     // (gp: K + 4 record values, then the blocks, then the ranks — see build_impl)
     u32 *pr2 = ranked ? e->gp.as<u32>() + 3 * (K + 4) : (u32*)e->KB.p, *pb2 = ranked ? e->gp.as<u32>() + 2 * (K + 4) : pr2 + (K + 4);
     unsigned char* flags = (unsigned char*)e->tbits.p + bit_words * 4;
+    phase_mark(e, st, "work list");
     KSP_HIP(hipMemsetAsync(e->tbits.p, 0, bit_words * 4 + T + 64, st));
     if (!(ranked && e->have_dwork)) {
         KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
@@ -647,9 +745,15 @@ int ksp_engine_create(int device, ksp_engine** out) {
     }
     ksp_engine* e = new ksp_engine();
     e->device = device;
-    KSP_HIP(hipHostMalloc((void**)&e->h_count, 64));
-    KSP_HIP(hipHostMalloc((void**)&e->h_scal, 128));
-    for (int i = 0; i < 6; ++i) KSP_HIP(hipEventCreate(&e->ev[i]));
+    hipError_t err = hipHostMalloc((void**)&e->h_count, 64);
+    if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_scal, 128);
+    for (int i = 0; i < 6 && err == hipSuccess; ++i) err = hipEventCreate(&e->ev[i]);
+    for (int i = 0; i < ksp_engine::kMaxPhase && err == hipSuccess; ++i) err = hipEventCreate(&e->ph_ev[i]);
+    if (err != hipSuccess) {
+        set_error(std::string("ksp_engine_create: ") + hipGetErrorString(err));
+        ksp_engine_destroy(e);   // (frees whatever was created)
+        return KSP_E_HIP;
+    }
     *out = e;
     return KSP_OK;
 }
@@ -659,12 +763,13 @@ void ksp_engine_destroy(ksp_engine* e) {
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
-                        &e->d_wg, &e->gp, &e->gm};
+                        &e->d_wg, &e->gp, &e->gm, &e->PK, &e->PT, &e->PD, &e->parena};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     for (int i = 0; i < 6; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    for (int i = 0; i < ksp_engine::kMaxPhase; ++i) if (e->ph_ev[i]) (void)hipEventDestroy(e->ph_ev[i]);
     delete e;
 }
 
@@ -788,6 +893,8 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     KSP_HIP(hipSetDevice(e->device));
     e->built = false;
     e->slice_ready = false;
+    e->sched_on = false; e->collect = false; e->have_bits = false;   // (nothing of the previous build's work list survives)
+    e->act_tid.clear(); e->act_rec.clear();
     for (u32 s = 0; s < n_sources; ++s)
         if (h_offsets[s + 1] < h_offsets[s]) { set_error("build: offsets not monotone"); return KSP_E_ARG; }
     const u64 n = n_sources ? h_offsets[n_sources] - h_offsets[0] : 0;
@@ -806,6 +913,9 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     if (std::getenv("KSP_FULL_SORT")) e->full_sort = true;   // diagnostic: sort on all key bits
     if (const char* hg = std::getenv("KSP_HASH_GROUP")) e->hash_off = std::atoi(hg) == 0;   // diagnostic / tests
     if (const char* kg = std::getenv("KSP_KEY_GROUPS")) e->key_groups_off = std::atoi(kg) == 0;
+    if (const char* pp = std::getenv("KSP_PARTITION")) e->part_off = std::string(pp) == "rocprim";   // diagnostic / tests
+    if (const char* pm = std::getenv("KSP_PART_MIN")) e->part_min = (u32)std::max(1, std::atoi(pm));
+    e->ph_n = 0;
     e->st = ksp_stats{};
     e->st.n_sources = n_sources;
     e->st.n_entries = n;
@@ -857,10 +967,12 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     KSP_HIP(hipEventRecord(e->ev[1], st));
     KSP_HIP(hipStreamSynchronize(st));
     KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
+    phase_close(e, e->ev[1]);
     e->st.key_bits = e->key_bits;
     e->st.ms_sort = 0;
     e->st.sort_entries = e->sort_entries;
     e->st.sort_bits = e->sort_bits;
+    e->st.partition_kind = e->sort_entries ? e->part_kind : 0;
     if (e->sort_entries) KSP_HIP(hipEventElapsedTime(&e->st.ms_sort, e->ev[4], e->ev[5]));
     return KSP_OK;
 }
@@ -872,6 +984,9 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
     KSP_HIP(hipSetDevice(e->device));
     e->built = false;
     e->slice_ready = false;
+    e->sched_on = false; e->collect = false; e->have_bits = false;
+    e->act_tid.clear(); e->act_rec.clear();
+    e->ph_n = 0;
     e->slice_phase = 0;
     const u64 n = n_keys ? h_key_off[n_keys] : 0;
     if (n_keys && h_key_off[0] != 0) { set_error("build_postings: key_off[0] must be 0"); return KSP_E_ARG; }
@@ -943,6 +1058,7 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
     KSP_HIP(hipEventRecord(e->ev[1], st));
     KSP_HIP(hipStreamSynchronize(st));
     KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
+    phase_close(e, e->ev[1]);
     return finish_build(e);
 }
 
@@ -1340,6 +1456,20 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
         return KSP_E_OVERFLOW;
     }
     return KSP_OK;
+}
+
+int ksp_engine_set_profiling(ksp_engine* e, int on) {
+    if (!e) return KSP_E_ARG;
+    e->profiling = on != 0;
+    e->ph_n = 0;
+    return KSP_OK;
+}
+
+int ksp_engine_phase_times(const ksp_engine* e, const char** names, float* ms, int cap) {
+    if (!e || cap < 0 || (cap && (!names || !ms))) return 0;
+    const int n = std::min(cap, e->ph_n);
+    for (int i = 0; i < n; ++i) { names[i] = e->ph_name[i]; ms[i] = e->ph_ms[i]; }
+    return n;
 }
 
 int ksp_engine_get_stats(const ksp_engine* e, ksp_stats* out) {

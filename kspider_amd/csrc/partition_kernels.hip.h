@@ -1,0 +1,357 @@
+// Stage 1, first step: the entries (key, source tag) are PARTITIONED by key into hash buckets of ~800
+// entries, which k_bucket_group then groups by full key in LDS.  Hand-written for gfx950; replaces the
+// rocPRIM radix partition (histogram pass + two 8-bit onesweep passes over 8-byte key + tag, and a
+// tagging pass in front of them).  Included by engine.hip inside namespace ksp.
+//
+// What the reference does here: src/pairwise.cpp:194-209 turns the colour map into a vector and cuts it
+// into per-thread slices — it brings the sources of equal colours together.  The sketch path has to bring
+// equal hashes together first; this is that step.
+//
+//   bucket(key) = floor(key * nbuckets / (maxkey + 1))          (one 64 x 64 -> high 64 multiply: monotone
+//                                                                in the key, uniform over the real hash
+//                                                                range, which is not a power of two)
+//   level 1  k_part1   one workgroup per 2 048 consecutive entries of the sketch array.  Every source's
+//            run is sorted, so the entries of one level-1 bucket (the top pb1 <= 8 bits of the bucket id)
+//            form runs of consecutive entries: a wave finds the run heads with one ballot, the head lane
+//            counts the run into an LDS histogram, and each (workgroup, bucket) pair reserves its place
+//            with ONE global atomic.  No histogram pass and no capacity guess: a level-1 bucket is a list
+//            of 4 096-entry PAGES taken from a pool on demand (the reservation that crosses a page start
+//            allocates that page and publishes it in the list's page table; nobody else ever waits for
+//            anything before publishing, so the short spin of the others cannot deadlock).  Each bucket
+//            has 8 sub-lists, chosen by blockIdx % 8 — workgroups b and b + 8 share an XCD, so the lines
+//            at a sub-list's tail are filled inside ONE L2 and reach HBM whole — and the 8 cursors of a
+//            bucket sit on memory lines of their own.  The source tag is made on the fly (no tagging
+//            pass); the low pb2 bits of the bucket id go to a byte array beside the keys.
+//   level 2  k_part2   one workgroup per level-1 bucket: pass 1 counts the entries of its <= 256 final
+//            buckets from the digit bytes (1/8 of the bytes of the keys), a scan gives every final bucket
+//            its exact place in the dense output (bstart[], what k_bucket_bounds used to search for);
+//            pass 2 streams the pages in tiles of 4 096 entries, orders a tile by bucket in LDS (counting
+//            sort with LDS atomics; the order inside a bucket is irrelevant) and writes it out in runs of
+//            ~16 entries per bucket — full lines, no global atomics.
+//
+// HBM traffic per entry (8-byte key, 2-byte tag): level 1 reads 8, writes 11; level 2 reads 1 + 10,
+// writes 10 — 40 bytes, against 8 + 2 (tagging) + 8 (histogram) + 2 x 20 (two passes) = 58 before.
+// Anything the page tables cannot hold (a key distribution more than ~16 x off uniform) raises the
+// overflow word: the build falls back to the rocPRIM partition, which stays in the engine.
+#pragma once
+
+constexpr u32 P1_CH = 2048, P1_THREADS = 256, P1_EPT = P1_CH / P1_THREADS;
+constexpr u32 P1_R = 8;           // sub-lists per level-1 bucket (one per XCD)
+constexpr u32 P1_LINE = 32;       // u32 words per cursor: a memory line of its own
+constexpr u32 P1_PLOG = 12;       // page = 4 096 entries
+constexpr u32 P1_PAGE = 1u << P1_PLOG;
+constexpr u32 P1_PTW_MAX = 128;   // page-table entries per sub-list
+constexpr u32 P2_THREADS = 1024, P2_TILE = 4096, P2_EPT = P2_TILE / P2_THREADS;
+// control words inside the engine's scalar block (u64 units): [0] largest key (k_max_last),
+// PC_MULT the multiplier, PC_MODE: low word 1 = identity buckets, PC_OVF: low word = overflow
+constexpr u32 PC_MULT = 12, PC_MODE = 13, PC_OVF = 14;
+
+__device__ inline u32 part_bucket(const u64 key, const u64 mult, const u32 ident, const u32 nbm1) {
+    return ident ? (u32)min(key, (u64)nbm1) : (u32)__umul64hi(key, mult);
+}
+
+// mult = floor(nbuckets * 2^64 / (maxkey + 1)); fewer key values than buckets: every key its own bucket
+__global__ void k_part_prep(u64* __restrict__ scal, const u32 nbuckets) {
+    if (blockIdx.x || threadIdx.x) return;
+    const u64 maxkey = scal[0];
+    u64 mult = 0;
+    u32 ident = 0;
+    if (maxkey <= (u64)nbuckets) ident = 1;
+    else if (maxkey == ~0ull) mult = nbuckets;                     // umulhi(key, 2^pb) = the top pb bits
+    else {
+        const u64 M = maxkey + 1;
+        u64 rem = nbuckets, q = 0;                                 // (nbuckets : 0) / M, nbuckets < M
+        for (int i = 63; i >= 0; --i) {
+            const u64 carry = rem >> 63;
+            rem <<= 1;
+            if (carry || rem >= M) { rem -= M; q |= 1ull << i; }
+        }
+        mult = q;
+    }
+    scal[PC_MULT] = mult;
+    reinterpret_cast<u32*>(scal + PC_MODE)[0] = ident;
+}
+
+// last source s with off[s] <= pos  (off[0] = 0 <= pos < off[n_sources])
+__device__ inline u32 part_source_of(const u64* __restrict__ off, const u32 n_sources, const u64 pos) {
+    u32 lo = 0, hi = n_sources;
+    while (hi - lo > 1) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (off[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ inline u32 part_wait_page(u32* __restrict__ pt, const u32 row, const u32 q, const u32 ptw, u32* __restrict__ ovf) {
+    if (q >= ptw) { __hip_atomic_store(ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return ~0u; }
+    for (u32 spin = 0; spin < (1u << 22); ++spin) {   // (bounded: a page that never comes ends as an overflow, not a hang)
+        const u32 x = __hip_atomic_load(&pt[row + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x) return x - 1;
+        if (__hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return ~0u;   // (its allocator gave up)
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __hip_atomic_store(ovf, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return ~0u;
+}
+
+template <class V>
+__global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ keys, const u64* __restrict__ off,
+                                                      const u32 n_sources, const u32 n, u64* __restrict__ scal,
+                                                      const int pb2, const u32 nbm1, const u32 ptw,
+                                                      u32* __restrict__ pools, u32* __restrict__ cursors,
+                                                      u32* __restrict__ pt, const u32 pool_pages,
+                                                      u64* __restrict__ Kp, V* __restrict__ Tp, u8* __restrict__ Dp) {
+    __shared__ __attribute__((aligned(16))) u32 s_src[P1_CH];
+    __shared__ u32 s_hist[256], s_base[256], s_pg0[256], s_pg1[256];
+    __shared__ u32 s_lohi[2], s_wmax[P1_THREADS / 64];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 c0 = blockIdx.x * P1_CH, cn = min(P1_CH, n - c0);
+    u64 key[P1_EPT];
+#pragma unroll
+    for (u32 j = 0; j < P1_EPT; ++j) {
+        const u32 idx = j * P1_THREADS + tid;
+        key[j] = idx < cn ? keys[c0 + idx] : 0;
+    }
+    const u64 mult = scal[PC_MULT];
+    const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
+    const u32 rsub = blockIdx.x & (P1_R - 1);                 // sub-list class: workgroups b and b + 8 share an XCD
+    u32* const pool = pools + (size_t)rsub * P1_LINE;         // (one page pool per class: a single word would see
+                                                              //  every page allocation of the launch)
+    u32* const ovf = reinterpret_cast<u32*>(scal + PC_OVF);
+    s_hist[tid] = 0;
+    if (tid < 2) s_lohi[tid] = part_source_of(off, n_sources, tid == 0 ? (u64)c0 : (u64)c0 + cn - 1);
+    __syncthreads();
+    const u32 s_lo = s_lohi[0], s_hi = s_lohi[1];
+    if (s_lo != s_hi) {   // several sources in this chunk: source of every entry = prefix maximum of the run starts
+        for (u32 i = tid; i < P1_CH; i += P1_THREADS) s_src[i] = 0;
+        __syncthreads();
+        if (tid == 0) s_src[0] = s_lo;
+        for (u32 s = s_lo + 1 + tid; s <= s_hi; s += P1_THREADS) {
+            const u64 o = off[s];
+            if (off[s + 1] > o) s_src[(u32)(o - c0)] = s;   // (non-empty sources start at distinct entries)
+        }
+        __syncthreads();
+        uint4 a = reinterpret_cast<uint4*>(s_src)[2 * tid], b = reinterpret_cast<uint4*>(s_src)[2 * tid + 1];
+        u32 v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (u32 q = 1; q < 8; ++q) v[q] = max(v[q], v[q - 1]);
+        u32 inc = v[7];
+        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc = max(inc, up); }
+        if (lane == 63) s_wmax[wv] = inc;
+        __syncthreads();
+        u32 before = __shfl_up(inc, 1);
+        if (lane == 0) before = 0;
+        for (u32 w = 0; w < wv; ++w) before = max(before, s_wmax[w]);
+#pragma unroll
+        for (u32 q = 0; q < 8; ++q) v[q] = max(v[q], before);
+        reinterpret_cast<uint4*>(s_src)[2 * tid] = make_uint4(v[0], v[1], v[2], v[3]);
+        reinterpret_cast<uint4*>(s_src)[2 * tid + 1] = make_uint4(v[4], v[5], v[6], v[7]);
+        __syncthreads();
+    }
+    // runs of equal level-1 bucket among 64 consecutive entries: the head lane counts the run
+    u32 info[P1_EPT];   // level-1 bucket | digit byte << 8 | place inside (workgroup, bucket) << 16
+#pragma unroll
+    for (u32 j = 0; j < P1_EPT; ++j) {
+        const u32 idx = j * P1_THREADS + tid;
+        const bool valid = idx < cn;
+        const u32 b = part_bucket(key[j], mult, ident, nbm1);
+        const u32 d1 = valid ? (b >> pb2) : 0x1FFu, d2 = b & ((1u << pb2) - 1u);
+        const u32 prev = __shfl_up(d1, 1);
+        const bool head = lane == 0 || prev != d1;
+        const unsigned long long hm = __ballot(head);
+        const unsigned long long upto = (2ull << lane) - 1ull;   // lanes <= mine (lane 63: all ones)
+        const u32 hl = 63u - (u32)__builtin_clzll(hm & upto);
+        const unsigned long long above = hm & ~upto;
+        const u32 nxt = above ? (u32)__builtin_ctzll(above) : 64u;
+        u32 rb = 0;
+        if (head && valid) rb = atomicAdd(&s_hist[d1], nxt - lane);
+        rb = __shfl(rb, hl);
+        info[j] = (d1 & 0xFFu) | (d2 << 8) | ((rb + lane - hl) << 16);
+    }
+    __syncthreads();
+    {   // one reservation per (workgroup, level-1 bucket); the one that crosses a page start allocates the page
+        const u32 cnt = s_hist[tid];
+        u32 v = 0, g0 = ~0u, g1 = ~0u;
+        if (cnt) {
+            const u32 L = tid * P1_R + rsub;
+            v = atomicAdd(&cursors[(size_t)L * P1_LINE], cnt);
+            const u32 q0 = v >> P1_PLOG, q1 = (v + cnt - 1) >> P1_PLOG;
+            const u32 mine = (v & (P1_PAGE - 1)) == 0 ? q0 : (q1 != q0 ? q1 : ~0u);
+            if (mine != ~0u) {
+                bool ok = false;
+                if (mine < ptw) {
+                    const u32 ph = atomicAdd(pool, 1u);
+                    if (ph < pool_pages) {
+                        __hip_atomic_store(&pt[(size_t)L * ptw + mine], rsub * pool_pages + ph + 1, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        ok = true;
+                    }
+                }
+                if (!ok) __hip_atomic_store(ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("" ::: "memory");   // (every lane has published its page before any lane starts to wait)
+            g0 = part_wait_page(pt, L * ptw, q0, ptw, ovf);
+            g1 = q1 == q0 ? g0 : part_wait_page(pt, L * ptw, q1, ptw, ovf);
+        }
+        s_base[tid] = v; s_pg0[tid] = g0; s_pg1[tid] = g1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 j = 0; j < P1_EPT; ++j) {
+        const u32 idx = j * P1_THREADS + tid;
+        if (idx >= cn) continue;
+        const u32 d1 = info[j] & 0xFFu, base = s_base[d1], v = base + (info[j] >> 16);
+        const u32 ph = (v >> P1_PLOG) == (base >> P1_PLOG) ? s_pg0[d1] : s_pg1[d1];
+        if (ph == ~0u) continue;   // (overflow: the build is repeated with the library partition)
+        const size_t a = ((size_t)ph << P1_PLOG) | (v & (P1_PAGE - 1));
+        const u32 src = s_lo == s_hi ? s_lo : s_src[idx];
+        Kp[a] = key[j];
+        Tp[a] = make_tag<V>(((src / TB) << 8) | (src % TB), 0u);
+        Dp[a] = (u8)(info[j] >> 8);
+    }
+}
+
+// list lengths (0 everywhere after an overflow: level 2 then leaves empty buckets behind and the host
+// repeats the build) and the start of every level-1 bucket in the dense output
+__global__ __launch_bounds__(256) void k_part_totals(const u32* __restrict__ cursors, u64* __restrict__ scal, const u32 nb1,
+                                                     const u32 ptw, const u32 n, u32* __restrict__ lens,
+                                                     u32* __restrict__ btot) {
+    __shared__ u32 s_w[4];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    u32* const ovf = reinterpret_cast<u32*>(scal + PC_OVF);
+    const bool bad = *ovf != 0;
+    u32 tot = 0;
+    if (tid < nb1)
+        for (u32 r = 0; r < P1_R; ++r) {
+            const u32 L = tid * P1_R + r;
+            const u32 c = bad ? 0u : cursors[(size_t)L * P1_LINE];
+            lens[L] = c;
+            tot += c;
+        }
+    u32 inc = tot;
+    for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    u32 run = inc - tot;
+    for (u32 w = 0; w < wv; ++w) run += s_w[w];
+    if (tid < nb1) btot[tid] = run;
+    if (tid == 255) {
+        btot[nb1] = run + tot;
+        if (!bad && run + tot != n) *ovf = 2;   // (cannot happen: every entry is counted exactly once)
+    }
+}
+
+template <class V>
+__global__ __launch_bounds__(P2_THREADS) void k_part2(const u64* __restrict__ scal, const u32* __restrict__ lens,
+                                                      const u32* __restrict__ btot, const u32* __restrict__ pt,
+                                                      const u32 ptw, const int pb2, const u32 nbm1,
+                                                      const u64* __restrict__ Kp, const V* __restrict__ Tp,
+                                                      const u8* __restrict__ Dp, u64* __restrict__ K2,
+                                                      V* __restrict__ T2, u32* __restrict__ bstart, const u32 nb1) {
+    __shared__ u64 s_key[P2_TILE];
+    __shared__ V s_tag[P2_TILE];
+    __shared__ u8 s_bin[P2_TILE];
+    __shared__ u32 s_pt[P1_R * P1_PTW_MAX];
+    __shared__ u32 s_len[P1_R];
+    __shared__ u32 s_hist[256], s_ls[256], s_cur[256], s_cnt[256];
+    const u32 B = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 nb2 = 1u << pb2;
+    const u64 mult = scal[PC_MULT];
+    const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
+    for (u32 i = tid; i < P1_R * ptw; i += P2_THREADS) s_pt[i] = pt[(size_t)B * P1_R * ptw + i];
+    if (tid < P1_R) s_len[tid] = lens[B * P1_R + tid];
+    if (tid < 256) { s_hist[tid] = 0; s_cnt[tid] = 0; }
+    __syncthreads();
+    // pass 1: entries per final bucket, from the digit bytes (four per load)
+    for (u32 r = 0; r < P1_R; ++r) {
+        const u32 len = s_len[r];
+        for (u32 v4 = 4 * tid; v4 < len; v4 += 4 * P2_THREADS) {
+            const u32 pg = s_pt[r * ptw + (v4 >> P1_PLOG)] - 1;
+            if (pg == ~0u) continue;   // (cannot happen: every reserved place has its page)
+            const u32 w = *reinterpret_cast<const u32*>(Dp + (((size_t)pg << P1_PLOG) | (v4 & (P1_PAGE - 1))));
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k)
+                if (v4 + k < len) atomicAdd(&s_hist[(w >> (8 * k)) & 0xFFu], 1u);
+        }
+    }
+    __syncthreads();
+    if (wv == 0) {   // 256 bins, four per lane: the exact start of every final bucket
+        u32 c[4], t = 0;
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) { c[i] = s_hist[4 * lane + i]; t += c[i]; }
+        u32 inc = t;
+        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+        u32 run = btot[B] + inc - t;
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) {
+            const u32 bin = 4 * lane + i;
+            s_cur[bin] = run;
+            if (bin < nb2) bstart[(size_t)B * nb2 + bin] = run;
+            run += c[i];
+        }
+    }
+    if (B == nb1 - 1 && tid == 0) bstart[(size_t)nb1 * nb2] = btot[nb1];
+    __syncthreads();
+    // pass 2: tile by tile — order the tile by bucket in LDS, write runs
+    for (u32 r = 0; r < P1_R; ++r) {
+        const u32 len = s_len[r];
+        for (u32 t0 = 0; t0 < len; t0 += P2_TILE) {
+            u64 key[P2_EPT];
+            V tag[P2_EPT];
+            u32 rk[P2_EPT];
+#pragma unroll
+            for (u32 k = 0; k < P2_EPT; ++k) {
+                const u32 v = t0 + k * P2_THREADS + tid;
+                key[k] = 0; tag[k] = V(0);
+                if (v < len) {
+                    const u32 pg = s_pt[r * ptw + (v >> P1_PLOG)] - 1;
+                    const size_t a = ((size_t)(pg == ~0u ? 0u : pg) << P1_PLOG) | (v & (P1_PAGE - 1));
+                    key[k] = Kp[a];
+                    tag[k] = Tp[a];
+                }
+            }
+#pragma unroll
+            for (u32 k = 0; k < P2_EPT; ++k) {
+                const u32 v = t0 + k * P2_THREADS + tid;
+                rk[k] = part_bucket(key[k], mult, ident, nbm1) & (nb2 - 1);
+                if (v < len) rk[k] |= atomicAdd(&s_cnt[rk[k]], 1u) << 8;
+            }
+            __syncthreads();
+            if (wv == 0) {
+                u32 c[4], t = 0;
+#pragma unroll
+                for (u32 i = 0; i < 4; ++i) { c[i] = s_cnt[4 * lane + i]; t += c[i]; }
+                u32 inc = t;
+                for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+                u32 run = inc - t;
+#pragma unroll
+                for (u32 i = 0; i < 4; ++i) { s_ls[4 * lane + i] = run; run += c[i]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (u32 k = 0; k < P2_EPT; ++k) {
+                const u32 v = t0 + k * P2_THREADS + tid;
+                if (v < len) {
+                    const u32 bin = rk[k] & 0xFFu, slot = s_ls[bin] + (rk[k] >> 8);
+                    s_key[slot] = key[k];
+                    s_tag[slot] = tag[k];
+                    s_bin[slot] = (u8)bin;
+                }
+            }
+            __syncthreads();
+            const u32 m = min(P2_TILE, len - t0);
+#pragma unroll
+            for (u32 k = 0; k < P2_EPT; ++k) {
+                const u32 i = k * P2_THREADS + tid;
+                if (i < m) {
+                    const u32 bin = s_bin[i], dst = s_cur[bin] + (i - s_ls[bin]);
+                    K2[dst] = s_key[i];
+                    T2[dst] = s_tag[i];
+                }
+            }
+            __syncthreads();
+            if (tid < 256) { s_cur[tid] += s_cnt[tid]; s_cnt[tid] = 0; }
+            __syncthreads();
+        }
+    }
+}

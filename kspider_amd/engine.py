@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "ksp_engine_build_slice", "ksp_engine_slice_sizes", "ksp_engine_slice_export", "ksp_engine_assemble",
     "ksp_engine_edge_bound", "ksp_engine_slice_labels", "ksp_engine_slice_finish", "ksp_engine_balanced_cuts",
     "ksp_engine_build_postings", "ksp_pairwise_postings_host",
+    "ksp_engine_set_profiling", "ksp_engine_phase_times",
 ]
 
 
@@ -39,6 +40,7 @@ class Stats(ctypes.Structure):
         ("ms_build", ctypes.c_float), ("ms_join", ctypes.c_float), ("weighted", ctypes.c_int),
         ("key_bits", ctypes.c_int), ("n_active_tiles", ctypes.c_uint64), ("last_active_tiles", ctypes.c_uint64),
         ("sort_entries", ctypes.c_uint64), ("ms_sort", ctypes.c_float), ("sort_bits", ctypes.c_int),
+        ("partition_kind", ctypes.c_int),
     ]
 
     def as_dict(self):
@@ -102,6 +104,9 @@ def lib():
                                                  ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                                  ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(Stats)]
         L.ksp_free.restype = None
+        L.ksp_engine_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.ksp_engine_phase_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p),
+                                             ctypes.POINTER(ctypes.c_float), ctypes.c_int]
         L.kspider_pairwise.argtypes = [ctypes.c_char_p, ctypes.c_int]
         L.ksp_index_info.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
         L.ksp_format_float.argtypes = [ctypes.c_float, ctypes.c_char_p]
@@ -282,6 +287,17 @@ class Engine:
         _check(lib().ksp_engine_join(self._h, t0, t1, d_edges_ptr or None, capacity, ctypes.byref(cnt),
                                      stream or None))
         return cnt.value
+
+    def set_profiling(self, on: bool = True):
+        """Record one HIP event per phase start of every later build (see phase_times)."""
+        _check(lib().ksp_engine_set_profiling(self._h, int(bool(on))))
+
+    def phase_times(self) -> list:
+        """[(phase name, ms)] of the last build made with profiling on."""
+        names = (ctypes.c_char_p * 24)()
+        ms = (ctypes.c_float * 24)()
+        n = lib().ksp_engine_phase_times(self._h, names, ms, 24)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
     def stats(self) -> dict:
         st = Stats()

@@ -29,6 +29,14 @@ def test_bench_line_and_two_rank_equivalence():
         assert k in one
     assert one["n_gpus"] == 1 and one["config"]["n_sources"] == 1500 and one["value"] > 0
     assert one["roofline"]["bound"] == "hbm" and one["roofline"]["peak"] == 8000.0
+    # a roofline FRACTION: recomputable from the line itself, never above 1
+    r = one["roofline"]
+    assert 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["achieved"] - r["bytes_per_step"] / (one["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["groups"] and {"partition", "join"} <= {g["group"] for g in r["groups"]}
+    assert all(g["ms"] > 0 for g in r["groups"])
+    assert one["naive_pairwise"]["bytes_per_step"] > r["bytes_per_step"]
+    assert one["config"]["buffers_regrown_in_timed_region"] == 0
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                 "--master-addr", "127.0.0.1", "--master-port", "29713", "bench.py", "--gpus", "2"] + common,
                {"KSP_BENCH_CHECKSUM": "1", "KSP_BENCH_SHARE_GPU": "1", "KSP_BENCH_BACKEND": "gloo"})

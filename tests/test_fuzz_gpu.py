@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 MODES = [{}, {"KSP_REORDER": "0"}, {"KSP_NO_SCHED": "1"}, {"KSP_COLLECT": "1"}, {"KSP_COLLECT": "0"},
          {"KSP_JOIN": "window"}, {"KSP_TAG32": "1"}, {"KSP_HASH_GROUP": "0"}, {"KSP_KEY_GROUPS": "0"},
-         {"KSP_KEY_GROUPS": "0", "KSP_REORDER": "0"}]
+         {"KSP_KEY_GROUPS": "0", "KSP_REORDER": "0"}, {"KSP_PART_MIN": "1"}, {"KSP_PARTITION": "rocprim"}]
 
 
 def _random_sketches(rng):
@@ -37,7 +37,8 @@ def test_random_sketches_all_modes(oracle_lib, seed, monkeypatch):
         sk = _random_sketches(rng)
         ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
         for env in MODES:
-            for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_JOIN", "KSP_TAG32", "KSP_HASH_GROUP", "KSP_KEY_GROUPS"):
+            for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_JOIN", "KSP_TAG32", "KSP_HASH_GROUP", "KSP_KEY_GROUPS",
+                      "KSP_PART_MIN", "KSP_PARTITION"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)

@@ -1,0 +1,112 @@
+"""The hand-written two-level partition of stage 1 (kspider_amd/csrc/partition_kernels.hip.h) against the
+brute-force oracle and against the rocPRIM partition it replaces: page boundaries, chunks that hold many
+sources (and empty ones), one source spanning many chunks, key ranges that are not powers of two, full 64-bit
+keys, fewer key values than buckets, and key distributions so far from uniform that the page tables
+overflow and the build must fall back — same edges every way."""
+import numpy as np
+import pytest
+
+from kspider_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _edges(sk, monkeypatch, **env):
+    for k in ("KSP_PARTITION", "KSP_PART_MIN"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    return engine.pairwise_host(sk.keys, sk.offsets)
+
+
+def _both(sk, monkeypatch, oracle=None, expect_hand=True):
+    hand, st = _edges(sk, monkeypatch, KSP_PART_MIN="1")
+    lib, st_lib = _edges(sk, monkeypatch, KSP_PARTITION="rocprim")
+    assert st_lib["partition_kind"] in (0, 1)
+    if expect_hand:
+        assert st["partition_kind"] == 2, st
+    assert len(hand) == len(lib) and (hand == lib).all()
+    if oracle is not None:
+        ref = oracle.brute_pairs(sk.keys, sk.offsets)
+        assert len(hand) == len(ref) and (hand == ref).all()
+    return hand, st
+
+
+def test_pages_chunks_and_ragged_sources(oracle_lib, monkeypatch):
+    """~1.6 M entries: lists of several pages, 2 048-entry chunks holding dozens of tiny sources, empty
+    sources in between, and one 300 000-entry source that spans ~150 chunks."""
+    rng = np.random.default_rng(7)
+    pool = rng.integers(0, (1 << 64) // 1000, size=400_000, dtype=np.uint64)
+    runs = []
+    for s in range(1200):
+        if s % 17 == 0:
+            runs.append(np.zeros(0, dtype=np.uint64))
+        elif s == 601:
+            runs.append(np.unique(np.concatenate([pool[:200_000], rng.integers(0, (1 << 64) // 1000, size=100_000, dtype=np.uint64)])))
+        elif s % 3 == 0:
+            runs.append(np.unique(pool[rng.integers(0, pool.size, size=int(rng.integers(1, 60)))]))
+        else:
+            fam = pool[(s % 7) * 50_000:(s % 7 + 1) * 50_000]
+            runs.append(np.unique(np.concatenate([fam[rng.random(fam.size) < 0.03],
+                                                  rng.integers(0, (1 << 64) // 1000, size=300, dtype=np.uint64)])))
+    sk = synth.from_runs(runs)
+    assert int(sk.offsets[-1]) > 1_500_000
+    _both(sk, monkeypatch, oracle_lib)
+
+
+@pytest.mark.parametrize("n_sources,size", [(3, 5), (40, 100), (513, 700), (2000, 2100)])
+def test_small_and_medium_sets(oracle_lib, monkeypatch, n_sources, size):
+    sk = synth.generate("C2", n_sources=n_sources, mean_size=size, cluster_cap=max(2, n_sources // 20), seed=900 + n_sources)
+    _both(sk, monkeypatch, oracle_lib)
+
+
+def test_full_width_keys_and_the_largest_key(oracle_lib, monkeypatch):
+    rng = np.random.default_rng(8)
+    top = np.uint64(0xFFFFFFFFFFFFFFFF)
+    runs = []
+    for s in range(300):
+        wide = rng.integers(0, 1 << 64, size=500, dtype=np.uint64)
+        extra = [top, np.uint64(0)] if s % 2 == 0 else [top - np.uint64(1), np.uint64(1) << np.uint64(63)]
+        runs.append(np.unique(np.concatenate([wide, np.array(extra, dtype=np.uint64)])))
+    _both(synth.from_runs(runs), monkeypatch, oracle_lib)
+
+
+def test_fewer_key_values_than_buckets(oracle_lib, monkeypatch):
+    """Keys 0..99 held by many sources each (a colour-id-like key space): every key is its own bucket."""
+    rng = np.random.default_rng(9)
+    runs = [np.unique(rng.integers(0, 100, size=int(rng.integers(5, 80)), dtype=np.uint64)) for _ in range(900)]
+    _both(synth.from_runs(runs), monkeypatch, oracle_lib, expect_hand=False)   # (may end on the sort path: huge buckets)
+
+
+def test_skewed_keys_overflow_the_page_tables_and_fall_back(oracle_lib, monkeypatch):
+    """Nearly all keys inside 1/100 000 of the key range: one level-1 bucket would need hundreds of pages, the
+    partition raises its overflow word and the same build is repeated with the library partition."""
+    rng = np.random.default_rng(10)
+    runs = []
+    for s in range(700):
+        low = rng.integers(0, 1 << 40, size=2500, dtype=np.uint64)
+        high = rng.integers(0, 1 << 57, size=20, dtype=np.uint64)
+        runs.append(np.unique(np.concatenate([low, high, np.arange(s % 5, 4000, 5, dtype=np.uint64)])))
+    sk = synth.from_runs(runs)
+    hand, st = _edges(sk, monkeypatch, KSP_PART_MIN="1")
+    assert st["partition_kind"] == 1, st          # fell back
+    ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
+    assert len(hand) == len(ref) and (hand == ref).all()
+
+
+def test_rebuilds_on_one_engine_give_the_same_edges(monkeypatch):
+    """The page pools, cursors and page tables are reset per build: ten builds on one engine, same edge set."""
+    sk = synth.generate("C2", n_sources=1500, mean_size=1500, cluster_cap=60, seed=321)
+    dk = engine.DeviceBuffer.from_numpy(sk.keys)
+    e = engine.Engine(0)
+    cap = 1 << 22
+    de = engine.DeviceBuffer(cap * 16)
+    first = None
+    for _ in range(10):
+        e.build_blocks(dk.ptr.value, sk.offsets)
+        assert e.stats()["partition_kind"] == 2
+        cnt = e.join(0, e.num_tiles, de.ptr.value, cap)
+        ev = np.sort(de.to_numpy(engine.EDGE_DTYPE, cnt), order=["source_1", "source_2"])
+        if first is None:
+            first = ev
+        assert len(ev) == len(first) and (ev == first).all()
