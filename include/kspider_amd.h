@@ -60,6 +60,9 @@ typedef struct ksp_stats {
     int partition_kind;         /* how the last build brought equal keys together: 0 nothing to do / postings
                                    input, 1 rocPRIM radix partition or sort, 2 the hand-written two-level
                                    partition (partition_kernels.hip.h)                                   */
+    int partition_fallback;     /* 0, or why the hand-written partition handed the build to rocPRIM: 1 page
+                                   table / pool full (keys far from uniform), 2 internal count mismatch,
+                                   3 page wait timed out — 2 and 3 are defects, never expected            */
 } ksp_stats;
 
 const char* ksp_last_error(void);

@@ -151,6 +151,7 @@ struct ksp_engine {
     u64 sort_entries = 0;                    // entries / key bits of the last global radix sort (stats)
     int sort_bits = 0;
     int part_kind = 0;                       // 1 rocPRIM, 2 hand-written partition (stats)
+    int part_fail = 0;                       // overflow word of the hand-written partition when it gave up (stats)
     u64 h_scal_words = 0, h_scal_keys = 0;   // list words / distinct shared keys of the lists being finished
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // build, join, first radix sort
     ksp_stats st{};
@@ -280,13 +281,14 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     // source tags itself: no read-back, no tagging pass.  Unweighted whole builds whose bucket count fits
     // its two levels; everything else (weighted sketches, key-range slices, > 2^16 buckets) takes the
     // rocPRIM partition below.
-    int pb_hand = 0;
+    u32 nb_hand = 0;   // buckets of the hand-written partition (any number up to 2^16; 0: not used)
     if (!W && phase == 0 && e->nparts == 1 && !e->hash_off && !e->full_sort && !e->part_off && n >= e->part_min) {
-        pb_hand = 1;
-        while ((n >> pb_hand) > HB_MEAN) ++pb_hand;
-        if (pb_hand > 16) pb_hand = 0;
+        u32 mean = HB_HAND_MEAN;
+        if (const char* bm = std::getenv("KSP_DEBUG_BUCKET_MEAN")) mean = (u32)std::max(64, std::atoi(bm));   // (timing experiments)
+        const u64 want = (n + mean - 1) / mean;
+        if (want <= 65536) nb_hand = (u32)std::max<u64>(1, want);
     }
-    const bool hand = pb_hand > 0;
+    const bool hand = nb_hand > 0;
     KSP_HIP(hipMemsetAsync(scal + 4, 0, 8 * 11, st));   // [4] .. [14]: overflow words, counters of the partition
     if (hand) {
         phase_mark(e, st, "key range + source sizes");
@@ -370,7 +372,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     //  which compare whole keys; folding the two halves of the key range keeps the buckets even)
     if (topbit > 63) topbit = 63;
     int pb = 0;
-    if (hand) pb = pb_hand;
+    if (hand) { pb = 1; while ((1u << pb) < nb_hand) ++pb; }   // (statistics; the hand-written partition takes any bucket count)
     else if ((phase == 0 || phase == 1) && !e->hash_off && !e->full_sort && nw >= 4096u) {
         pb = 1;
         while ((nw >> pb) > HB_MEAN) ++pb;
@@ -380,7 +382,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     u32* first = (u32*)e->FK.p;            // first kept entry of every rank (FK: the slice's input keys are dead after sort 1)
     if (pb) {
         const int shiftb = topbit - pb;
-        const u32 nbuckets = 1u << pb;
+        const u32 nbuckets = hand ? nb_hand : 1u << pb;
         // KB is free until the grouping scans: per-entry records, then the bucket tables
         u32* rec = (u32*)e->KB.p;
         u64* bsum = (u64*)e->KB.p + (nw / 2 + 1);
@@ -389,33 +391,42 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         u32* d_hovf = (u32*)(scal + 9);
         if (hand) {
             // two-level partition by bucket = floor(key * nbuckets / (max key + 1)): d_keys -> pages -> KA, VB, bstart
-            const int pb1 = std::min(pb, 8), pb2 = pb - pb1;
-            const u32 nb1 = 1u << pb1, lists = nb1 * P1_R;
+            int pb2 = 0;
+            while (((nbuckets + (1u << pb2) - 1) >> pb2) > 256) ++pb2;
+            const u32 nb1 = (nbuckets + (1u << pb2) - 1) >> pb2, lists = nb1 * P1_R;
             const u32 ptw = (u32)std::min<u64>(P1_PTW_MAX, 16 * (((nw / lists) >> P1_PLOG) + 1) + 16);
             const u64 per_r = nw / P1_R;
             const u32 pool_r = (u32)((per_r >> P1_PLOG) + (per_r >> (P1_PLOG + 3)) + nb1 + 8);   // pages per sub-list class
             const size_t pages = (size_t)pool_r * P1_R;
+            const u32 nchunks = grid_for(nw, P1_CH);
             if ((rc = e->PK.ensure(pages * P1_PAGE * 8))) return rc;
             if ((rc = e->PT.ensure(pages * P1_PAGE * sizeof(V)))) return rc;
             if ((rc = e->PD.ensure(pages * P1_PAGE))) return rc;
-            // arena: pools (one line each), cursors (one line each), page tables | list lengths, bucket starts
-            const size_t zero_words = (size_t)P1_R * P1_LINE + (size_t)lists * P1_LINE + (size_t)lists * ptw;
-            if ((rc = e->parena.ensure((zero_words + lists + nb1 + 2) * 4))) return rc;
+            // arena: pools (one line each), cursors (one line each), page tables, page owners | list lengths, level-1
+            // starts, per-bucket cursors, chunk sources
+            const size_t zero_words = (size_t)P1_R * P1_LINE + (size_t)lists * P1_LINE + (size_t)lists * ptw + pages;
+            if ((rc = e->parena.ensure((zero_words + lists + nb1 + 2 + (size_t)nbuckets + 1 + nchunks + 2) * 4))) return rc;
             u32* pools = e->parena.as<u32>();
             u32* cursors = pools + (size_t)P1_R * P1_LINE;
             u32* ptab = cursors + (size_t)lists * P1_LINE;
-            u32* lens = ptab + (size_t)lists * ptw;
+            u32* owner = ptab + (size_t)lists * ptw;
+            u32* lens = owner + pages;
             u32* btot = lens + lists;
+            u32* gcur = btot + (nb1 + 2);
+            u32* src_tbl = gcur + ((size_t)nbuckets + 1);
             phase_mark(e, st, "partition");
             KSP_HIP(hipEventRecord(e->ev[4], st));
             KSP_HIP(hipMemsetAsync(pools, 0, zero_words * 4, st));
             hipLaunchKernelGGL(k_part_prep, dim3(1), dim3(64), 0, st, scal, nbuckets);
-            hipLaunchKernelGGL((k_part1<V>), dim3(grid_for(nw, P1_CH)), dim3(P1_THREADS), 0, st, d_keys, d_off, N, (u32)nw,
-                               scal, pb2, nbuckets - 1, ptw, pools, cursors, ptab, pool_r, e->PK.as<u64>(), e->PT.as<V>(),
-                               e->PD.as<u8>());
+            hipLaunchKernelGGL(k_part_src, dim3(grid_for((u64)nchunks + 1, bs)), dim3(bs), 0, st, d_off, N, nchunks, src_tbl);
+            hipLaunchKernelGGL((k_part1<V>), dim3(nchunks), dim3(P1_THREADS), 0, st, d_keys, d_off, N, (u32)nw, scal, pb2,
+                               nbuckets - 1, ptw, pools, cursors, ptab, pool_r, src_tbl, owner, e->PK.as<u64>(),
+                               e->PT.as<V>(), e->PD.as<u8>());
             hipLaunchKernelGGL(k_part_totals, dim3(1), dim3(256), 0, st, cursors, scal, nb1, ptw, (u32)nw, lens, btot);
-            hipLaunchKernelGGL((k_part2<V>), dim3(nb1), dim3(P2_THREADS), 0, st, scal, lens, btot, ptab, ptw, pb2,
-                               nbuckets - 1, e->PK.as<u64>(), e->PT.as<V>(), e->PD.as<u8>(), KA, VB, bstart, nb1);
+            hipLaunchKernelGGL(k_hist2, dim3(nb1), dim3(PH_THREADS), 0, st, lens, btot, ptab, ptw, pb2, nbuckets,
+                               e->PD.as<u8>(), bstart, gcur, nb1);
+            hipLaunchKernelGGL((k_scatter2<V>), dim3((u32)pages), dim3(P2_THREADS), 0, st, scal, lens, owner, ptw, pb2,
+                               nbuckets - 1, e->PK.as<u64>(), e->PT.as<V>(), gcur, KA, VB);
             KSP_HIP(hipEventRecord(e->ev[5], st));
             phase_mark(e, st, "bucket grouping");
             KSP_HIP(hipMemsetAsync(bsum, 0, (size_t)nbuckets * 8, st));
@@ -459,6 +470,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         if (hand) {
             if ((u32)e->h_scal[PC_OVF]) {   // the page tables could not hold these keys: the library partition from now on
                 e->part_off = true;
+                e->part_fail = (int)(u32)e->h_scal[PC_OVF];
                 return build_impl<V>(e, d_keys, d_w, st, phase);
             }
             e->max_key = e->h_scal[0];
@@ -913,7 +925,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     if (std::getenv("KSP_FULL_SORT")) e->full_sort = true;   // diagnostic: sort on all key bits
     if (const char* hg = std::getenv("KSP_HASH_GROUP")) e->hash_off = std::atoi(hg) == 0;   // diagnostic / tests
     if (const char* kg = std::getenv("KSP_KEY_GROUPS")) e->key_groups_off = std::atoi(kg) == 0;
-    if (const char* pp = std::getenv("KSP_PARTITION")) e->part_off = std::string(pp) == "rocprim";   // diagnostic / tests
+    if (const char* pp = std::getenv("KSP_PARTITION")) { e->part_off = std::string(pp) == "rocprim"; e->part_fail = 0; }   // diagnostic / tests
     if (const char* pm = std::getenv("KSP_PART_MIN")) e->part_min = (u32)std::max(1, std::atoi(pm));
     e->ph_n = 0;
     e->st = ksp_stats{};
@@ -973,6 +985,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     e->st.sort_entries = e->sort_entries;
     e->st.sort_bits = e->sort_bits;
     e->st.partition_kind = e->sort_entries ? e->part_kind : 0;
+    e->st.partition_fallback = e->part_fail;
     if (e->sort_entries) KSP_HIP(hipEventElapsedTime(&e->st.ms_sort, e->ev[4], e->ev[5]));
     return KSP_OK;
 }

@@ -1,4 +1,4 @@
-// Stage 1, first step: the entries (key, source tag) are PARTITIONED by key into hash buckets of ~800
+// Stage 1, first step: the entries (key, source tag) are PARTITIONED by key into hash buckets of ~1 400
 // entries, which k_bucket_group then groups by full key in LDS.  Hand-written for gfx950; replaces the
 // rocPRIM radix partition (histogram pass + two 8-bit onesweep passes over 8-byte key + tag, and a
 // tagging pass in front of them).  Included by engine.hip inside namespace ksp.
@@ -9,25 +9,27 @@
 //
 //   bucket(key) = floor(key * nbuckets / (maxkey + 1))          (one 64 x 64 -> high 64 multiply: monotone
 //                                                                in the key, uniform over the real hash
-//                                                                range, which is not a power of two)
-//   level 1  k_part1   one workgroup per 2 048 consecutive entries of the sketch array.  Every source's
-//            run is sorted, so the entries of one level-1 bucket (the top pb1 <= 8 bits of the bucket id)
+//                                                                range, which is not a power of two; any
+//                                                                bucket count, not just powers of two)
+//   level 1  k_part1   one workgroup per 4 096 consecutive entries of the sketch array.  Every source's
+//            run is sorted, so the entries of one level-1 bucket (bucket id >> pb2, at most 256 of them)
 //            form runs of consecutive entries: a wave finds the run heads with one ballot, the head lane
 //            counts the run into an LDS histogram, and each (workgroup, bucket) pair reserves its place
 //            with ONE global atomic.  No histogram pass and no capacity guess: a level-1 bucket is a list
 //            of 4 096-entry PAGES taken from a pool on demand (the reservation that crosses a page start
 //            allocates that page and publishes it in the list's page table; nobody else ever waits for
-//            anything before publishing, so the short spin of the others cannot deadlock).  Each bucket
-//            has 8 sub-lists, chosen by blockIdx % 8 — workgroups b and b + 8 share an XCD, so the lines
-//            at a sub-list's tail are filled inside ONE L2 and reach HBM whole — and the 8 cursors of a
-//            bucket sit on memory lines of their own.  The source tag is made on the fly (no tagging
-//            pass); the low pb2 bits of the bucket id go to a byte array beside the keys.
-//   level 2  k_part2   one workgroup per level-1 bucket: pass 1 counts the entries of its <= 256 final
-//            buckets from the digit bytes (1/8 of the bytes of the keys), a scan gives every final bucket
-//            its exact place in the dense output (bstart[], what k_bucket_bounds used to search for);
-//            pass 2 streams the pages in tiles of 4 096 entries, orders a tile by bucket in LDS (counting
-//            sort with LDS atomics; the order inside a bucket is irrelevant) and writes it out in runs of
-//            ~16 entries per bucket — full lines, no global atomics.
+//            anything before publishing, so the short, bounded spin of the others cannot deadlock).  Each
+//            bucket has 8 sub-lists, chosen by blockIdx % 8 — workgroups b and b + 8 share an XCD, so the
+//            lines at a sub-list's tail are filled inside ONE L2 — with cursors and page pools on memory
+//            lines of their own.  The source tag is made on the fly (no tagging pass; the chunk's first
+//            source comes from a table built by k_part_src); the low pb2 bits of the bucket id go to a byte
+//            array beside the keys.
+//   level 2  k_hist2   one workgroup per level-1 bucket counts the entries of its <= 256 final buckets from
+//            the digit bytes (1/8 of the bytes of the keys); a scan gives every final bucket its exact place
+//            in the dense output (bstart[], what k_bucket_bounds used to search for).
+//            k_scatter2   one workgroup per PAGE: orders its 4 096 entries by final bucket in LDS (counting
+//            sort with LDS atomics; the order inside a bucket is irrelevant), reserves the run of every
+//            bucket with one global atomic on that bucket's cursor and writes the runs out.
 //
 // HBM traffic per entry (8-byte key, 2-byte tag): level 1 reads 8, writes 11; level 2 reads 1 + 10,
 // writes 10 — 40 bytes, against 8 + 2 (tagging) + 8 (histogram) + 2 x 20 (two passes) = 58 before.
@@ -35,13 +37,14 @@
 // overflow word: the build falls back to the rocPRIM partition, which stays in the engine.
 #pragma once
 
-constexpr u32 P1_CH = 2048, P1_THREADS = 256, P1_EPT = P1_CH / P1_THREADS;
+constexpr u32 P1_CH = 4096, P1_THREADS = 512, P1_EPT = P1_CH / P1_THREADS;
 constexpr u32 P1_R = 8;           // sub-lists per level-1 bucket (one per XCD)
 constexpr u32 P1_LINE = 32;       // u32 words per cursor: a memory line of its own
 constexpr u32 P1_PLOG = 12;       // page = 4 096 entries
 constexpr u32 P1_PAGE = 1u << P1_PLOG;
 constexpr u32 P1_PTW_MAX = 128;   // page-table entries per sub-list
-constexpr u32 P2_THREADS = 1024, P2_TILE = 4096, P2_EPT = P2_TILE / P2_THREADS;
+constexpr u32 P2_THREADS = 512, P2_TILE = P1_PAGE, P2_EPT = P2_TILE / P2_THREADS;   // one page per workgroup
+constexpr u32 PH_THREADS = 1024;
 // control words inside the engine's scalar block (u64 units): [0] largest key (k_max_last),
 // PC_MULT the multiplier, PC_MODE: low word 1 = identity buckets, PC_OVF: low word = overflow
 constexpr u32 PC_MULT = 12, PC_MODE = 13, PC_OVF = 14;
@@ -94,23 +97,32 @@ __device__ inline u32 part_wait_page(u32* __restrict__ pt, const u32 row, const 
     return ~0u;
 }
 
+// source of the first entry of every chunk (tbl[nchunks] = the last source): the bisection is done once, by a
+// kernel of its own, instead of sitting at the start of every chunk's critical path
+__global__ void k_part_src(const u64* __restrict__ off, const u32 n_sources, const u32 nchunks, u32* __restrict__ tbl) {
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > nchunks) return;
+    tbl[c] = c < nchunks ? part_source_of(off, n_sources, (u64)c * P1_CH) : n_sources - 1;
+}
+
 template <class V>
 __global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ keys, const u64* __restrict__ off,
                                                       const u32 n_sources, const u32 n, u64* __restrict__ scal,
                                                       const int pb2, const u32 nbm1, const u32 ptw,
                                                       u32* __restrict__ pools, u32* __restrict__ cursors,
                                                       u32* __restrict__ pt, const u32 pool_pages,
+                                                      const u32* __restrict__ src_tbl, u32* __restrict__ owner,
                                                       u64* __restrict__ Kp, V* __restrict__ Tp, u8* __restrict__ Dp) {
     __shared__ __attribute__((aligned(16))) u32 s_src[P1_CH];
     __shared__ u32 s_hist[256], s_base[256], s_pg0[256], s_pg1[256];
-    __shared__ u32 s_lohi[2], s_wmax[P1_THREADS / 64];
+    __shared__ u32 s_wmax[P1_THREADS / 64];
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 c0 = blockIdx.x * P1_CH, cn = min(P1_CH, n - c0);
     u64 key[P1_EPT];
 #pragma unroll
     for (u32 j = 0; j < P1_EPT; ++j) {
         const u32 idx = j * P1_THREADS + tid;
-        key[j] = idx < cn ? keys[c0 + idx] : 0;
+        key[j] = idx < cn ? __builtin_nontemporal_load(keys + c0 + idx) : 0;   // (read once)
     }
     const u64 mult = scal[PC_MULT];
     const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
@@ -118,17 +130,17 @@ __global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ ke
     u32* const pool = pools + (size_t)rsub * P1_LINE;         // (one page pool per class: a single word would see
                                                               //  every page allocation of the launch)
     u32* const ovf = reinterpret_cast<u32*>(scal + PC_OVF);
-    s_hist[tid] = 0;
-    if (tid < 2) s_lohi[tid] = part_source_of(off, n_sources, tid == 0 ? (u64)c0 : (u64)c0 + cn - 1);
-    __syncthreads();
-    const u32 s_lo = s_lohi[0], s_hi = s_lohi[1];
+    if (tid < 256) s_hist[tid] = 0;
+    // first source of this chunk and of the next (the last entry's source is that one or an earlier one)
+    const u32 s_lo = src_tbl[blockIdx.x], s_hi = src_tbl[blockIdx.x + 1];
+    __syncthreads();   // (the histogram is zero before any wave counts into it)
     if (s_lo != s_hi) {   // several sources in this chunk: source of every entry = prefix maximum of the run starts
         for (u32 i = tid; i < P1_CH; i += P1_THREADS) s_src[i] = 0;
         __syncthreads();
         if (tid == 0) s_src[0] = s_lo;
         for (u32 s = s_lo + 1 + tid; s <= s_hi; s += P1_THREADS) {
-            const u64 o = off[s];
-            if (off[s + 1] > o) s_src[(u32)(o - c0)] = s;   // (non-empty sources start at distinct entries)
+            const u64 o = off[s];   // (> c0: s_lo is the last source that starts at or before the chunk)
+            if (off[s + 1] > o && o < (u64)c0 + cn) s_src[(u32)(o - c0)] = s;   // (non-empty sources start at distinct entries)
         }
         __syncthreads();
         uint4 a = reinterpret_cast<uint4*>(s_src)[2 * tid], b = reinterpret_cast<uint4*>(s_src)[2 * tid + 1];
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ ke
         info[j] = (d1 & 0xFFu) | (d2 << 8) | ((rb + lane - hl) << 16);
     }
     __syncthreads();
-    {   // one reservation per (workgroup, level-1 bucket); the one that crosses a page start allocates the page
+    if (tid < 256) {   // one reservation per (workgroup, level-1 bucket); the one that crosses a page start allocates the page
         const u32 cnt = s_hist[tid];
         u32 v = 0, g0 = ~0u, g1 = ~0u;
         if (cnt) {
@@ -182,6 +194,7 @@ __global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ ke
                 if (mine < ptw) {
                     const u32 ph = atomicAdd(pool, 1u);
                     if (ph < pool_pages) {
+                        owner[rsub * pool_pages + ph] = L * ptw + mine + 1;   // (read by level 2, after this kernel)
                         __hip_atomic_store(&pt[(size_t)L * ptw + mine], rsub * pool_pages + ph + 1, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
                         ok = true;
@@ -241,31 +254,23 @@ __global__ __launch_bounds__(256) void k_part_totals(const u32* __restrict__ cur
     }
 }
 
-template <class V>
-__global__ __launch_bounds__(P2_THREADS) void k_part2(const u64* __restrict__ scal, const u32* __restrict__ lens,
-                                                      const u32* __restrict__ btot, const u32* __restrict__ pt,
-                                                      const u32 ptw, const int pb2, const u32 nbm1,
-                                                      const u64* __restrict__ Kp, const V* __restrict__ Tp,
-                                                      const u8* __restrict__ Dp, u64* __restrict__ K2,
-                                                      V* __restrict__ T2, u32* __restrict__ bstart, const u32 nb1) {
-    __shared__ u64 s_key[P2_TILE];
-    __shared__ V s_tag[P2_TILE];
-    __shared__ u8 s_bin[P2_TILE];
+// level 2, counting: one workgroup per level-1 bucket B — entries per final bucket from the digit bytes (four
+// per load), the exact start of every final bucket (bstart) and the cursors the scatter reserves from (gcur)
+__global__ __launch_bounds__(PH_THREADS) void k_hist2(const u32* __restrict__ lens, const u32* __restrict__ btot,
+                                                      const u32* __restrict__ pt, const u32 ptw, const int pb2,
+                                                      const u32 nbuckets, const u8* __restrict__ Dp,
+                                                      u32* __restrict__ bstart, u32* __restrict__ gcur, const u32 nb1) {
     __shared__ u32 s_pt[P1_R * P1_PTW_MAX];
     __shared__ u32 s_len[P1_R];
-    __shared__ u32 s_hist[256], s_ls[256], s_cur[256], s_cnt[256];
+    __shared__ u32 s_hist[256];
     const u32 B = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u32 nb2 = 1u << pb2;
-    const u64 mult = scal[PC_MULT];
-    const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
-    for (u32 i = tid; i < P1_R * ptw; i += P2_THREADS) s_pt[i] = pt[(size_t)B * P1_R * ptw + i];
+    for (u32 i = tid; i < P1_R * ptw; i += PH_THREADS) s_pt[i] = pt[(size_t)B * P1_R * ptw + i];
     if (tid < P1_R) s_len[tid] = lens[B * P1_R + tid];
-    if (tid < 256) { s_hist[tid] = 0; s_cnt[tid] = 0; }
+    if (tid < 256) s_hist[tid] = 0;
     __syncthreads();
-    // pass 1: entries per final bucket, from the digit bytes (four per load)
     for (u32 r = 0; r < P1_R; ++r) {
         const u32 len = s_len[r];
-        for (u32 v4 = 4 * tid; v4 < len; v4 += 4 * P2_THREADS) {
+        for (u32 v4 = 4 * tid; v4 < len; v4 += 4 * PH_THREADS) {
             const u32 pg = s_pt[r * ptw + (v4 >> P1_PLOG)] - 1;
             if (pg == ~0u) continue;   // (cannot happen: every reserved place has its page)
             const u32 w = *reinterpret_cast<const u32*>(Dp + (((size_t)pg << P1_PLOG) | (v4 & (P1_PAGE - 1))));
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_part2(const u64* __restrict__ sc
         }
     }
     __syncthreads();
-    if (wv == 0) {   // 256 bins, four per lane: the exact start of every final bucket
+    if (wv == 0) {   // 256 bins, four per lane
         u32 c[4], t = 0;
 #pragma unroll
         for (u32 i = 0; i < 4; ++i) { c[i] = s_hist[4 * lane + i]; t += c[i]; }
@@ -284,74 +289,85 @@ __global__ __launch_bounds__(P2_THREADS) void k_part2(const u64* __restrict__ sc
         u32 run = btot[B] + inc - t;
 #pragma unroll
         for (u32 i = 0; i < 4; ++i) {
-            const u32 bin = 4 * lane + i;
-            s_cur[bin] = run;
-            if (bin < nb2) bstart[(size_t)B * nb2 + bin] = run;
+            const u32 b = (B << pb2) + 4 * lane + i;
+            if (4 * lane + i < (1u << pb2) && b < nbuckets) { bstart[b] = run; gcur[b] = run; }
             run += c[i];
         }
     }
-    if (B == nb1 - 1 && tid == 0) bstart[(size_t)nb1 * nb2] = btot[nb1];
+    if (B == nb1 - 1 && tid == 0) bstart[nbuckets] = btot[nb1];
+}
+
+// level 2, scatter: one workgroup per page.  owner[page] = (sub-list, index in its page table) + 1, 0 = unused.
+template <class V>
+__global__ __launch_bounds__(P2_THREADS) void k_scatter2(const u64* __restrict__ scal, const u32* __restrict__ lens,
+                                                         const u32* __restrict__ owner, const u32 ptw, const int pb2,
+                                                         const u32 nbm1, const u64* __restrict__ Kp,
+                                                         const V* __restrict__ Tp, u32* __restrict__ gcur,
+                                                         u64* __restrict__ K2, V* __restrict__ T2) {
+    __shared__ u64 s_key[P2_TILE];
+    __shared__ V s_tag[P2_TILE];
+    __shared__ u8 s_bin[P2_TILE];
+    __shared__ u32 s_ls[256], s_cnt[256], s_gb[256];
+    const u32 ow = owner[blockIdx.x];
+    if (!ow) return;
+    const u32 L = (ow - 1) / ptw, q = (ow - 1) % ptw, len = lens[L];
+    if (len <= (q << P1_PLOG)) return;   // (after an overflow the lengths are zero)
+    const u32 m = min(P1_PAGE, len - (q << P1_PLOG));
+    const u32 B = L / P1_R, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 nb2m1 = (1u << pb2) - 1u;
+    const u64 mult = scal[PC_MULT];
+    const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
+    const size_t page = (size_t)blockIdx.x << P1_PLOG;
+    u64 key[P2_EPT];
+    V tag[P2_EPT];
+    u32 rk[P2_EPT];
+#pragma unroll
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        key[k] = 0; tag[k] = V(0);
+        if (i < m) { key[k] = __builtin_nontemporal_load(Kp + page + i); tag[k] = __builtin_nontemporal_load(Tp + page + i); }
+    }
+    if (tid < 256) s_cnt[tid] = 0;
     __syncthreads();
-    // pass 2: tile by tile — order the tile by bucket in LDS, write runs
-    for (u32 r = 0; r < P1_R; ++r) {
-        const u32 len = s_len[r];
-        for (u32 t0 = 0; t0 < len; t0 += P2_TILE) {
-            u64 key[P2_EPT];
-            V tag[P2_EPT];
-            u32 rk[P2_EPT];
 #pragma unroll
-            for (u32 k = 0; k < P2_EPT; ++k) {
-                const u32 v = t0 + k * P2_THREADS + tid;
-                key[k] = 0; tag[k] = V(0);
-                if (v < len) {
-                    const u32 pg = s_pt[r * ptw + (v >> P1_PLOG)] - 1;
-                    const size_t a = ((size_t)(pg == ~0u ? 0u : pg) << P1_PLOG) | (v & (P1_PAGE - 1));
-                    key[k] = Kp[a];
-                    tag[k] = Tp[a];
-                }
-            }
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        rk[k] = part_bucket(key[k], mult, ident, nbm1) & nb2m1;
+        if (i < m) rk[k] |= atomicAdd(&s_cnt[rk[k]], 1u) << 8;
+    }
+    __syncthreads();
+    if (wv == 0) {   // where every bucket's run starts inside the tile
+        u32 c[4], t = 0;
 #pragma unroll
-            for (u32 k = 0; k < P2_EPT; ++k) {
-                const u32 v = t0 + k * P2_THREADS + tid;
-                rk[k] = part_bucket(key[k], mult, ident, nbm1) & (nb2 - 1);
-                if (v < len) rk[k] |= atomicAdd(&s_cnt[rk[k]], 1u) << 8;
-            }
-            __syncthreads();
-            if (wv == 0) {
-                u32 c[4], t = 0;
+        for (u32 i = 0; i < 4; ++i) { c[i] = s_cnt[4 * lane + i]; t += c[i]; }
+        u32 inc = t;
+        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+        u32 run = inc - t;
 #pragma unroll
-                for (u32 i = 0; i < 4; ++i) { c[i] = s_cnt[4 * lane + i]; t += c[i]; }
-                u32 inc = t;
-                for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
-                u32 run = inc - t;
+        for (u32 i = 0; i < 4; ++i) { s_ls[4 * lane + i] = run; run += c[i]; }
+    } else if (tid - 64 < 256) {   // ... and in the dense output: one atomic per bucket present in the tile
+        const u32 bin = tid - 64, c = s_cnt[bin];
+        if (c) s_gb[bin] = atomicAdd(&gcur[(B << pb2) + bin], c);
+    }
+    __syncthreads();
 #pragma unroll
-                for (u32 i = 0; i < 4; ++i) { s_ls[4 * lane + i] = run; run += c[i]; }
-            }
-            __syncthreads();
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        if (i < m) {
+            const u32 bin = rk[k] & 0xFFu, slot = s_ls[bin] + (rk[k] >> 8);
+            s_key[slot] = key[k];
+            s_tag[slot] = tag[k];
+            s_bin[slot] = (u8)bin;
+        }
+    }
+    __syncthreads();
 #pragma unroll
-            for (u32 k = 0; k < P2_EPT; ++k) {
-                const u32 v = t0 + k * P2_THREADS + tid;
-                if (v < len) {
-                    const u32 bin = rk[k] & 0xFFu, slot = s_ls[bin] + (rk[k] >> 8);
-                    s_key[slot] = key[k];
-                    s_tag[slot] = tag[k];
-                    s_bin[slot] = (u8)bin;
-                }
-            }
-            __syncthreads();
-            const u32 m = min(P2_TILE, len - t0);
-#pragma unroll
-            for (u32 k = 0; k < P2_EPT; ++k) {
-                const u32 i = k * P2_THREADS + tid;
-                if (i < m) {
-                    const u32 bin = s_bin[i], dst = s_cur[bin] + (i - s_ls[bin]);
-                    K2[dst] = s_key[i];
-                    T2[dst] = s_tag[i];
-                }
-            }
-            __syncthreads();
-            if (tid < 256) { s_cur[tid] += s_cnt[tid]; s_cnt[tid] = 0; }
-            __syncthreads();
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        if (i < m) {
+            const u32 bin = s_bin[i], dst = s_gb[bin] + (i - s_ls[bin]);
+            K2[dst] = s_key[i];
+            T2[dst] = s_tag[i];
         }
     }
 }

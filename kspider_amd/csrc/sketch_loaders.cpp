@@ -101,8 +101,8 @@ std::string read_maybe_gz(const std::string& path) {
     int n;
     while ((n = gzread(f, buf, sizeof buf)) > 0) out.append(buf, (size_t)n);
     const bool bad = n < 0;
-    gzclose(f);
-    if (bad) throw std::runtime_error("kspider_amd: read error on " + path);
+    const int rc = gzclose(f);   // (Z_BUF_ERROR: the compressed stream ends early)
+    if (bad || rc != Z_OK) throw std::runtime_error("kspider_amd: read error on " + path + " (truncated or corrupt gzip?)");
     return out;
 }
 
@@ -111,6 +111,7 @@ struct Json {
     const char* p;
     const char* end;
     const std::string& path;
+    int depth = 0;   // nesting of skip(): untrusted input must not be able to exhaust the stack
     [[noreturn]] void fail(const char* what) const {
         throw std::runtime_error("kspider_amd: " + path + ": malformed JSON (" + what + ")");
     }
@@ -121,7 +122,11 @@ struct Json {
         need('"');
         std::string s;
         while (p < end && *p != '"') {
-            if (*p == '\\') { ++p; if (p >= end) fail("escape"); if (*p == 'u') { p += 4; s += '?'; } else s += *p; }
+            if (*p == '\\') {
+                ++p;
+                if (p >= end) fail("escape");
+                if (*p == 'u') { if (end - p < 5) fail("escape"); p += 4; s += '?'; } else s += *p;
+            }
             else s += *p;
             ++p;
         }
@@ -133,18 +138,18 @@ struct Json {
         ws();
         if (p >= end) fail("eof");
         if (*p == '"') { str(); return; }
-        if (*p == '{') {
+        if (*p == '{' || *p == '[') {
+            if (++depth > 512) fail("nesting too deep");
+            const bool obj = *p == '{';
             ++p;
-            if (eat('}')) return;
-            do { str(); need(':'); skip(); } while (eat(','));
-            need('}');
-            return;
-        }
-        if (*p == '[') {
-            ++p;
-            if (eat(']')) return;
-            do { skip(); } while (eat(','));
-            need(']');
+            if (!eat(obj ? '}' : ']')) {
+                do {
+                    if (obj) { str(); need(':'); }
+                    skip();
+                } while (eat(','));
+                need(obj ? '}' : ']');
+            }
+            --depth;
             return;
         }
         while (p < end && *p != ',' && *p != '}' && *p != ']' && *p != ' ' && *p != '\n' && *p != '\t' && *p != '\r') ++p;

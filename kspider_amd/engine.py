@@ -40,7 +40,7 @@ class Stats(ctypes.Structure):
         ("ms_build", ctypes.c_float), ("ms_join", ctypes.c_float), ("weighted", ctypes.c_int),
         ("key_bits", ctypes.c_int), ("n_active_tiles", ctypes.c_uint64), ("last_active_tiles", ctypes.c_uint64),
         ("sort_entries", ctypes.c_uint64), ("ms_sort", ctypes.c_float), ("sort_bits", ctypes.c_int),
-        ("partition_kind", ctypes.c_int),
+        ("partition_kind", ctypes.c_int), ("partition_fallback", ctypes.c_int),
     ]
 
     def as_dict(self):

@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import dataclasses
 import math
+import os
 
 import numpy as np
 
@@ -110,7 +111,7 @@ def _sizes(law, seed, n):
 
 def generate(config: str = "C2", n_sources: int | None = None, seed: int | None = None,
              shuffle: bool = True, mean_size: int | None = None,
-             cluster_cap: int | None = None) -> SketchSet:
+             cluster_cap: int | None = None, workers: int | None = None) -> SketchSet:
     """Build the sketch set for one BASELINE config.
 
     ``n_sources`` overrides N (tests shrink the configs; the multi-GPU bench grows
@@ -163,9 +164,58 @@ def generate(config: str = "C2", n_sources: int | None = None, seed: int | None 
 
     order = np.argsort(cluster, kind="stable")
     bounds = np.searchsorted(cluster[order], np.arange(nclusters + 1))
-    runs: list = [None] * n
     mean_n = float(sizes.mean())
-    for c in range(nclusters):
+    ctx = (seed, hmax, sizes, d, borrow, second, order, bounds, mean_n)
+    # clusters are independent (every draw is a stateless function of (seed, stream, index)): large sets are
+    # generated by a few forked workers, each taking a contiguous range of clusters of about equal cost; the
+    # result does not depend on the number of workers
+    if workers is None:
+        workers = int(os.environ.get("KSP_SYNTH_WORKERS", "0")) or min(12, len(os.sched_getaffinity(0)))
+    if n < 20_000 or nclusters < 4 * workers:
+        workers = 1
+    if workers > 1:
+        cmax = np.maximum.reduceat(sizes[order], bounds[:-1][np.diff(bounds) > 0]) if n else np.zeros(0)
+        nonempty = np.flatnonzero(np.diff(bounds) > 0)
+        cost = np.zeros(nclusters)
+        cost[nonempty] = np.diff(bounds)[nonempty] * np.maximum(mean_n, cmax) + 2000.0 * np.diff(bounds)[nonempty]
+        acc = np.cumsum(cost)
+        parts_n = 4 * workers
+        cuts = [0] + [int(np.searchsorted(acc, acc[-1] * k / parts_n)) for k in range(1, parts_n)] + [nclusters]
+        tasks = [(cuts[k], cuts[k + 1]) for k in range(parts_n) if cuts[k + 1] > cuts[k]]
+        global _GEN_CTX
+        _GEN_CTX = ctx
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool_:
+            results = pool_.map(_gen_clusters, tasks, chunksize=1)
+        _GEN_CTX = None
+    else:
+        results = [_gen_range(ctx, 0, nclusters)]
+    lens = np.zeros(n, dtype=np.int64)
+    for ids, ls, _ in results:
+        lens[ids] = ls
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens, dtype=np.uint64)
+    keys = np.empty(int(offsets[-1]), dtype=np.uint64)
+    for ids, ls, ks in results:
+        pos = 0
+        for s, l in zip(ids.tolist(), ls.tolist()):
+            keys[int(offsets[s]):int(offsets[s]) + l] = ks[pos:pos + l]
+            pos += l
+    return SketchSet(keys, offsets, cluster, name=f"{config}(N={n})")
+
+
+_GEN_CTX = None
+
+
+def _gen_clusters(task):
+    return _gen_range(_GEN_CTX, task[0], task[1])
+
+
+def _gen_range(ctx, c_lo: int, c_hi: int):
+    """Sketches of clusters [c_lo, c_hi): (source ids, run lengths, concatenated sorted-unique runs)."""
+    seed, hmax, sizes, d, borrow, second, order, bounds, mean_n = ctx
+    ids, lens, runs = [], [], []
+    for c in range(c_lo, c_hi):
         members = order[bounds[c]:bounds[c + 1]]
         if members.size == 0:
             continue
@@ -188,14 +238,12 @@ def generate(config: str = "C2", n_sources: int | None = None, seed: int | None 
                 pool2 = _stream(seed, 1000 + 2 * c2, j2) % hmax
                 pick2 = _uniform01(seed ^ (s * 0xC2B2AE35 & 0x7FFFFFFF), 43, j2) < min(1.0, 0.1 * ns / pool2_n)
                 parts.append(pool2[pick2])
-            runs[s] = np.unique(np.concatenate(parts))
-    for s in range(n):
-        if runs[s] is None:      # cannot happen (every source has a cluster), kept for safety
-            runs[s] = np.zeros(0, dtype=np.uint64)
-    offsets = np.zeros(n + 1, dtype=np.uint64)
-    offsets[1:] = np.cumsum([r.size for r in runs], dtype=np.uint64)
-    keys = np.concatenate(runs).astype(np.uint64) if n else np.zeros(0, dtype=np.uint64)
-    return SketchSet(keys, offsets, cluster, name=f"{config}(N={n})")
+            r = np.unique(np.concatenate(parts))
+            ids.append(s)
+            lens.append(r.size)
+            runs.append(r)
+    return (np.asarray(ids, dtype=np.int64), np.asarray(lens, dtype=np.int64),
+            np.concatenate(runs).astype(np.uint64) if runs else np.zeros(0, dtype=np.uint64))
 
 
 def from_runs(runs, name: str = "custom") -> SketchSet:

@@ -23,8 +23,9 @@ def _both(sk, monkeypatch, oracle=None, expect_hand=True):
     hand, st = _edges(sk, monkeypatch, KSP_PART_MIN="1")
     lib, st_lib = _edges(sk, monkeypatch, KSP_PARTITION="rocprim")
     assert st_lib["partition_kind"] in (0, 1)
+    assert st["partition_fallback"] in (0, 1), st      # (2 / 3 would be defects of the partition itself)
     if expect_hand:
-        assert st["partition_kind"] == 2, st
+        assert st["partition_kind"] == 2 and st["partition_fallback"] == 0, st
     assert len(hand) == len(lib) and (hand == lib).all()
     if oracle is not None:
         ref = oracle.brute_pairs(sk.keys, sk.offsets)
@@ -89,7 +90,7 @@ def test_skewed_keys_overflow_the_page_tables_and_fall_back(oracle_lib, monkeypa
         runs.append(np.unique(np.concatenate([low, high, np.arange(s % 5, 4000, 5, dtype=np.uint64)])))
     sk = synth.from_runs(runs)
     hand, st = _edges(sk, monkeypatch, KSP_PART_MIN="1")
-    assert st["partition_kind"] == 1, st          # fell back
+    assert st["partition_kind"] == 1 and st["partition_fallback"] == 1, st          # fell back: page tables full
     ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
     assert len(hand) == len(ref) and (hand == ref).all()
 
