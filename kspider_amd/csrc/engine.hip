@@ -402,30 +402,28 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             if ((rc = e->PK.ensure(pages * P1_PAGE * 8))) return rc;
             if ((rc = e->PT.ensure(pages * P1_PAGE * sizeof(V)))) return rc;
             if ((rc = e->PD.ensure(pages * P1_PAGE))) return rc;
-            // arena: pools (one line each), cursors (one line each), page tables, page owners | list lengths, level-1
-            // starts, per-bucket cursors, chunk sources
-            const size_t zero_words = (size_t)P1_R * P1_LINE + (size_t)lists * P1_LINE + (size_t)lists * ptw + pages;
-            if ((rc = e->parena.ensure((zero_words + lists + nb1 + 2 + (size_t)nbuckets + 1 + nchunks + 2) * 4))) return rc;
+            // arena (zeroed per build): pools and cursors (one line each), page tables, page owners, bucket counters |
+            // chunk sources
+            const size_t zero_words = (size_t)P1_R * P1_LINE + (size_t)lists * P1_LINE + (size_t)lists * ptw + pages +
+                                      ((size_t)nbuckets + 1);
+            if ((rc = e->parena.ensure((zero_words + nchunks + 2) * 4))) return rc;
             u32* pools = e->parena.as<u32>();
             u32* cursors = pools + (size_t)P1_R * P1_LINE;
             u32* ptab = cursors + (size_t)lists * P1_LINE;
             u32* owner = ptab + (size_t)lists * ptw;
-            u32* lens = owner + pages;
-            u32* btot = lens + lists;
-            u32* gcur = btot + (nb1 + 2);
+            u32* gcur = owner + pages;
             u32* src_tbl = gcur + ((size_t)nbuckets + 1);
             phase_mark(e, st, "partition");
             KSP_HIP(hipEventRecord(e->ev[4], st));
             KSP_HIP(hipMemsetAsync(pools, 0, zero_words * 4, st));
-            hipLaunchKernelGGL(k_part_prep, dim3(1), dim3(64), 0, st, scal, nbuckets);
-            hipLaunchKernelGGL(k_part_src, dim3(grid_for((u64)nchunks + 1, bs)), dim3(bs), 0, st, d_off, N, nchunks, src_tbl);
+            hipLaunchKernelGGL(k_part_src, dim3(grid_for((u64)nchunks + 1, bs)), dim3(bs), 0, st, d_off, N, nchunks, src_tbl,
+                               scal, nbuckets);
             hipLaunchKernelGGL((k_part1<V>), dim3(nchunks), dim3(P1_THREADS), 0, st, d_keys, d_off, N, (u32)nw, scal, pb2,
                                nbuckets - 1, ptw, pools, cursors, ptab, pool_r, src_tbl, owner, e->PK.as<u64>(),
                                e->PT.as<V>(), e->PD.as<u8>());
-            hipLaunchKernelGGL(k_part_totals, dim3(1), dim3(256), 0, st, cursors, scal, nb1, ptw, (u32)nw, lens, btot);
-            hipLaunchKernelGGL(k_hist2, dim3(nb1), dim3(PH_THREADS), 0, st, lens, btot, ptab, ptw, pb2, nbuckets,
-                               e->PD.as<u8>(), bstart, gcur, nb1);
-            hipLaunchKernelGGL((k_scatter2<V>), dim3((u32)pages), dim3(P2_THREADS), 0, st, scal, lens, owner, ptw, pb2,
+            hipLaunchKernelGGL(k_hist2, dim3((u32)pages), dim3(256), 0, st, scal, cursors, owner, ptw, pb2, e->PD.as<u8>(), gcur);
+            hipLaunchKernelGGL(k_scan2, dim3(nb1), dim3(256), 0, st, scal, cursors, pb2, nbuckets, nb1, (u32)nw, gcur, bstart);
+            hipLaunchKernelGGL((k_scatter2<V>), dim3((u32)pages), dim3(P2_THREADS), 0, st, scal, cursors, owner, ptw, pb2,
                                nbuckets - 1, e->PK.as<u64>(), e->PT.as<V>(), gcur, KA, VB);
             KSP_HIP(hipEventRecord(e->ev[5], st));
             phase_mark(e, st, "bucket grouping");

@@ -1,4 +1,4 @@
-// Stage 1, first step: the entries (key, source tag) are PARTITIONED by key into hash buckets of ~1 400
+// Stage 1, first step: the entries (key, source tag) are PARTITIONED by key into hash buckets of ~2 000
 // entries, which k_bucket_group then groups by full key in LDS.  Hand-written for gfx950; replaces the
 // rocPRIM radix partition (histogram pass + two 8-bit onesweep passes over 8-byte key + tag, and a
 // tagging pass in front of them).  Included by engine.hip inside namespace ksp.
@@ -44,7 +44,7 @@ constexpr u32 P1_PLOG = 12;       // page = 4 096 entries
 constexpr u32 P1_PAGE = 1u << P1_PLOG;
 constexpr u32 P1_PTW_MAX = 128;   // page-table entries per sub-list
 constexpr u32 P2_THREADS = 512, P2_TILE = P1_PAGE, P2_EPT = P2_TILE / P2_THREADS;   // one page per workgroup
-constexpr u32 PH_THREADS = 1024;
+
 // control words inside the engine's scalar block (u64 units): [0] largest key (k_max_last),
 // PC_MULT the multiplier, PC_MODE: low word 1 = identity buckets, PC_OVF: low word = overflow
 constexpr u32 PC_MULT = 12, PC_MODE = 13, PC_OVF = 14;
@@ -54,13 +54,12 @@ __device__ inline u32 part_bucket(const u64 key, const u64 mult, const u32 ident
 }
 
 // mult = floor(nbuckets * 2^64 / (maxkey + 1)); fewer key values than buckets: every key its own bucket
-__global__ void k_part_prep(u64* __restrict__ scal, const u32 nbuckets) {
-    if (blockIdx.x || threadIdx.x) return;
+__device__ inline void part_prep(u64* __restrict__ scal, const u32 nbuckets) {
     const u64 maxkey = scal[0];
     u64 mult = 0;
     u32 ident = 0;
     if (maxkey <= (u64)nbuckets) ident = 1;
-    else if (maxkey == ~0ull) mult = nbuckets;                     // umulhi(key, 2^pb) = the top pb bits
+    else if (maxkey == ~0ull) mult = nbuckets;                     // umulhi(key, nbuckets): the top fraction of the key
     else {
         const u64 M = maxkey + 1;
         u64 rem = nbuckets, q = 0;                                 // (nbuckets : 0) / M, nbuckets < M
@@ -99,8 +98,10 @@ __device__ inline u32 part_wait_page(u32* __restrict__ pt, const u32 row, const 
 
 // source of the first entry of every chunk (tbl[nchunks] = the last source): the bisection is done once, by a
 // kernel of its own, instead of sitting at the start of every chunk's critical path
-__global__ void k_part_src(const u64* __restrict__ off, const u32 n_sources, const u32 nchunks, u32* __restrict__ tbl) {
+__global__ void k_part_src(const u64* __restrict__ off, const u32 n_sources, const u32 nchunks, u32* __restrict__ tbl,
+                           u64* __restrict__ scal, const u32 nbuckets) {
     const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) part_prep(scal, nbuckets);   // (the multiplier of this build, from the key range k_max_last found)
     if (c > nchunks) return;
     tbl[c] = c < nchunks ? part_source_of(off, n_sources, (u64)c * P1_CH) : n_sources - 1;
 }
@@ -224,82 +225,68 @@ __global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ ke
     }
 }
 
-// list lengths (0 everywhere after an overflow: level 2 then leaves empty buckets behind and the host
-// repeats the build) and the start of every level-1 bucket in the dense output
-__global__ __launch_bounds__(256) void k_part_totals(const u32* __restrict__ cursors, u64* __restrict__ scal, const u32 nb1,
-                                                     const u32 ptw, const u32 n, u32* __restrict__ lens,
-                                                     u32* __restrict__ btot) {
-    __shared__ u32 s_w[4];
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    u32* const ovf = reinterpret_cast<u32*>(scal + PC_OVF);
-    const bool bad = *ovf != 0;
-    u32 tot = 0;
-    if (tid < nb1)
-        for (u32 r = 0; r < P1_R; ++r) {
-            const u32 L = tid * P1_R + r;
-            const u32 c = bad ? 0u : cursors[(size_t)L * P1_LINE];
-            lens[L] = c;
-            tot += c;
-        }
-    u32 inc = tot;
+// level 2, counting: one workgroup per page — entries per final bucket from the page's 4 096 digit bytes
+// (an LDS histogram, then one global add per bucket present).  gcnt is zero at launch.
+__global__ __launch_bounds__(256) void k_hist2(const u64* __restrict__ scal, const u32* __restrict__ cursors,
+                                               const u32* __restrict__ owner, const u32 ptw, const int pb2,
+                                               const u8* __restrict__ Dp, u32* __restrict__ gcnt) {
+    __shared__ u32 s_hist[256];
+    const u32 ow = owner[blockIdx.x];
+    if (!ow || reinterpret_cast<const u32*>(scal + PC_OVF)[0]) return;   // (after an overflow: nothing is counted, every bucket stays empty)
+    const u32 L = (ow - 1) / ptw, q = (ow - 1) % ptw, len = cursors[(size_t)L * P1_LINE];
+    if (len <= (q << P1_PLOG)) return;
+    const u32 m = min(P1_PAGE, len - (q << P1_PLOG)), tid = threadIdx.x;
+    s_hist[tid] = 0;
+    __syncthreads();
+    const u32 i0 = 16 * tid;
+    if (i0 < m) {
+        const uint4 w4 = *reinterpret_cast<const uint4*>(Dp + ((size_t)blockIdx.x << P1_PLOG) + i0);
+        const u32 w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (u32 k = 0; k < 16; ++k)
+            if (i0 + k < m) atomicAdd(&s_hist[(w[k >> 2] >> (8 * (k & 3))) & 0xFFu], 1u);
+    }
+    __syncthreads();
+    const u32 c = s_hist[tid];
+    if (c) atomicAdd(&gcnt[((L / P1_R) << pb2) + tid], c);
+}
+
+// the exact start of every final bucket in the dense output: one workgroup per level-1 bucket B sums the lists in
+// front of it (every entry was counted exactly once by its list's cursor) and scans its own <= 256 buckets.
+// Writes bstart (what k_bucket_bounds used to search for) and turns gcnt into the cursors of the scatter.
+__global__ __launch_bounds__(256) void k_scan2(u64* __restrict__ scal, const u32* __restrict__ cursors, const int pb2,
+                                               const u32 nbuckets, const u32 nb1, const u32 n, u32* __restrict__ gcnt,
+                                               u32* __restrict__ bstart) {
+    __shared__ u32 s_w[4], s_base;
+    const u32 B = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool bad = reinterpret_cast<const u32*>(scal + PC_OVF)[0] != 0;
+    u32 before = 0;   // entries of the level-1 buckets in front of B
+    for (u32 L = tid; L < B * P1_R; L += 256) before += bad ? 0u : cursors[(size_t)L * P1_LINE];
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
+    if (lane == 0) s_w[wv] = before;
+    __syncthreads();
+    if (tid == 0) s_base = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+    const u32 b = (B << pb2) + tid;
+    const bool in = tid < (1u << pb2) && b < nbuckets;
+    const u32 c = in ? gcnt[b] : 0u;
+    u32 inc = c;
     for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
-    u32 run = inc - tot;
+    u32 run = s_base + inc - c;
     for (u32 w = 0; w < wv; ++w) run += s_w[w];
-    if (tid < nb1) btot[tid] = run;
-    if (tid == 255) {
-        btot[nb1] = run + tot;
-        if (!bad && run + tot != n) *ovf = 2;   // (cannot happen: every entry is counted exactly once)
+    if (in) { bstart[b] = run; gcnt[b] = run; }
+    if (B == nb1 - 1 && tid == 255) {
+        const u32 total = run + c;   // (thread 255 holds the inclusive sum over the whole workgroup: the grand total)
+        bstart[nbuckets] = total;
+        if (!bad && total != n) reinterpret_cast<u32*>(scal + PC_OVF)[0] = 2;   // (cannot happen: a defect, reported as such)
     }
-}
-
-// level 2, counting: one workgroup per level-1 bucket B — entries per final bucket from the digit bytes (four
-// per load), the exact start of every final bucket (bstart) and the cursors the scatter reserves from (gcur)
-__global__ __launch_bounds__(PH_THREADS) void k_hist2(const u32* __restrict__ lens, const u32* __restrict__ btot,
-                                                      const u32* __restrict__ pt, const u32 ptw, const int pb2,
-                                                      const u32 nbuckets, const u8* __restrict__ Dp,
-                                                      u32* __restrict__ bstart, u32* __restrict__ gcur, const u32 nb1) {
-    __shared__ u32 s_pt[P1_R * P1_PTW_MAX];
-    __shared__ u32 s_len[P1_R];
-    __shared__ u32 s_hist[256];
-    const u32 B = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (u32 i = tid; i < P1_R * ptw; i += PH_THREADS) s_pt[i] = pt[(size_t)B * P1_R * ptw + i];
-    if (tid < P1_R) s_len[tid] = lens[B * P1_R + tid];
-    if (tid < 256) s_hist[tid] = 0;
-    __syncthreads();
-    for (u32 r = 0; r < P1_R; ++r) {
-        const u32 len = s_len[r];
-        for (u32 v4 = 4 * tid; v4 < len; v4 += 4 * PH_THREADS) {
-            const u32 pg = s_pt[r * ptw + (v4 >> P1_PLOG)] - 1;
-            if (pg == ~0u) continue;   // (cannot happen: every reserved place has its page)
-            const u32 w = *reinterpret_cast<const u32*>(Dp + (((size_t)pg << P1_PLOG) | (v4 & (P1_PAGE - 1))));
-#pragma unroll
-            for (u32 k = 0; k < 4; ++k)
-                if (v4 + k < len) atomicAdd(&s_hist[(w >> (8 * k)) & 0xFFu], 1u);
-        }
-    }
-    __syncthreads();
-    if (wv == 0) {   // 256 bins, four per lane
-        u32 c[4], t = 0;
-#pragma unroll
-        for (u32 i = 0; i < 4; ++i) { c[i] = s_hist[4 * lane + i]; t += c[i]; }
-        u32 inc = t;
-        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
-        u32 run = btot[B] + inc - t;
-#pragma unroll
-        for (u32 i = 0; i < 4; ++i) {
-            const u32 b = (B << pb2) + 4 * lane + i;
-            if (4 * lane + i < (1u << pb2) && b < nbuckets) { bstart[b] = run; gcur[b] = run; }
-            run += c[i];
-        }
-    }
-    if (B == nb1 - 1 && tid == 0) bstart[nbuckets] = btot[nb1];
 }
 
 // level 2, scatter: one workgroup per page.  owner[page] = (sub-list, index in its page table) + 1, 0 = unused.
 template <class V>
-__global__ __launch_bounds__(P2_THREADS) void k_scatter2(const u64* __restrict__ scal, const u32* __restrict__ lens,
+__global__ __launch_bounds__(P2_THREADS) void k_scatter2(const u64* __restrict__ scal, const u32* __restrict__ cursors,
                                                          const u32* __restrict__ owner, const u32 ptw, const int pb2,
                                                          const u32 nbm1, const u64* __restrict__ Kp,
                                                          const V* __restrict__ Tp, u32* __restrict__ gcur,
@@ -309,9 +296,9 @@ __global__ __launch_bounds__(P2_THREADS) void k_scatter2(const u64* __restrict__
     __shared__ u8 s_bin[P2_TILE];
     __shared__ u32 s_ls[256], s_cnt[256], s_gb[256];
     const u32 ow = owner[blockIdx.x];
-    if (!ow) return;
-    const u32 L = (ow - 1) / ptw, q = (ow - 1) % ptw, len = lens[L];
-    if (len <= (q << P1_PLOG)) return;   // (after an overflow the lengths are zero)
+    if (!ow || reinterpret_cast<const u32*>(scal + PC_OVF)[0]) return;   // (after an overflow the build is repeated)
+    const u32 L = (ow - 1) / ptw, q = (ow - 1) % ptw, len = cursors[(size_t)L * P1_LINE];
+    if (len <= (q << P1_PLOG)) return;
     const u32 m = min(P1_PAGE, len - (q << P1_PLOG));
     const u32 B = L / P1_R, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 nb2m1 = (1u << pb2) - 1u;
