@@ -164,12 +164,24 @@ int ksp_pairwise_postings_host(const uint64_t* key_off, const uint32_t* sources,
                                uint32_t n_keys, uint32_t n_sources, int device, ksp_edge** out_edges,
                                uint64_t* n_edges, ksp_stats* stats);
 void ksp_free(void* p);
+/* The same two jobs on several GPUs of one node, one host thread and one engine per device (devices[] may name a
+ * device twice: two engines share it — used by the single-GPU tests).  This is what $KSPIDER_DEVICES selects
+ * behind kspider_pairwise() / kSpider::pairwise() (north star: the N x N pair space sharded over the GPUs of a
+ * node): sketch input is built in hash-range slices, one per device, exchanged device to device; an inverted
+ * index is built on every device; every device joins a tile range of equal estimated work; the edges are
+ * gathered to devices[0] (peer copies over xGMI), sorted there and returned in pinned host memory.        */
+int ksp_pairwise_host_multi(const uint64_t* keys, const uint32_t* weights, const uint64_t* offsets, uint32_t n_sources,
+                            const int* devices, int n_devices, ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats);
+int ksp_pairwise_postings_host_multi(const uint64_t* key_off, const uint32_t* sources, const uint32_t* key_weights,
+                                     uint32_t n_keys, uint32_t n_sources, const int* devices, int n_devices,
+                                     ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats);
 
 /* ---- the reference entry point ------------------------------------------------------
  * Same contract as kSpider::pairwise(string index_prefix, int user_threads)
  * (include/kSpider.hpp:11): reads PREFIX_color_to_sources.bin, PREFIX_color_count.bin,
  * PREFIX_groupID_to_kmerCount.bin, writes PREFIX_kSpider_seqToKmersNo.tsv and
- * PREFIX_kSpider_pairwise.tsv.  Device = $KSPIDER_DEVICE (default 0).                  */
+ * PREFIX_kSpider_pairwise.tsv.  Device = $KSPIDER_DEVICE (default 0); $KSPIDER_DEVICES=0,1,...
+ * shards the job over several GPUs (ksp_pairwise_postings_host_multi) — same output files.      */
 int kspider_pairwise(const char* index_prefix, int user_threads);
 
 /* ---- direct sketch inputs ----------------------------------

@@ -21,7 +21,12 @@
 //
 // Integer set intersection: no MFMA.  See DESIGN.md for the data layout, the measurements and the history.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <set>
+#include <thread>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -1524,133 +1529,337 @@ int ksp_memcpy_d2h(void* h, const void* d, uint64_t bytes) {
     return KSP_OK;
 }
 
-void ksp_free(void* p) { std::free(p); }
+// results handed to the caller live in pinned host memory (the device-to-host copy runs at the full link
+// rate straight into the buffer the caller gets); ksp_free tells them from malloc'ed blocks by this registry
+static std::mutex g_pinned_mu;
+static std::set<void*> g_pinned;
+static void* alloc_result(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(g_pinned_mu);
+    g_pinned.insert(p);
+    return p;
+}
+void ksp_free(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(g_pinned_mu);
+        auto it = g_pinned.find(p);
+        if (it != g_pinned.end()) { g_pinned.erase(it); (void)hipHostFree(p); return; }
+    }
+    std::free(p);
+}
 
-// join every tile of a built engine and bring the edges to the host, sorted by (source_1, source_2)
-static int collect_all_edges(ksp_engine* e, int device, ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats) {
-    void* d_edges = nullptr;
-    std::vector<ksp_edge> all;
+// ---- collecting the result: join -> [gather to the first device over xGMI] -> device sort -> pinned host ----
+// edges of tiles [t0, t1) of a built engine into a device buffer that grows to the size the join reports
+static int join_range_grow(ksp_engine* e, u64 t0, u64 t1, Buf& buf, u64& count, float& ms_join) {
+    count = 0;
+    if (t0 >= t1) return KSP_OK;
+    int rc;
+    if (buf.bytes < sizeof(ksp_edge)) {
+        const u64 first = std::min<u64>(ksp_engine_edge_bound(e, t0, t1) + 1, 1ull << 26);   // at most 1 GiB to begin with
+        if ((rc = buf.ensure(first * sizeof(ksp_edge)))) return rc;
+    }
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        u64 cnt = 0;
+        rc = ksp_engine_join(e, t0, t1, buf.as<ksp_edge>(), buf.bytes / sizeof(ksp_edge), &cnt, nullptr);
+        ms_join += e->st.ms_join;
+        if (rc == KSP_OK) { count = cnt; return KSP_OK; }
+        if (rc != KSP_E_OVERFLOW) return rc;
+        if ((rc = buf.ensure((cnt + cnt / 16 + 1024) * sizeof(ksp_edge)))) {   // (the count the join reported, plus slack)
+            set_error("pairwise_host: the edges of this tile range do not fit in device memory");
+            return KSP_E_LIMIT;
+        }
+    }
+    set_error("pairwise_host: edge count kept growing between joins");
+    return KSP_E_HIP;
+}
+
+__global__ void k_edge_split(const ksp_edge* __restrict__ ed, u64 n, u64* __restrict__ key, u64* __restrict__ val) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const ksp_edge x = ed[i];
+        key[i] = ((u64)x.source_1 << 32) | x.source_2;
+        val[i] = x.shared;
+    }
+}
+__global__ void k_edge_merge(const u64* __restrict__ key, const u64* __restrict__ val, u64 n, ksp_edge* __restrict__ ed) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        ksp_edge x;
+        x.source_1 = (u32)(key[i] >> 32);
+        x.source_2 = (u32)key[i];
+        x.shared = val[i];
+        ed[i] = x;
+    }
+}
+// rows in (source_1, source_2) order — the order the TSV writer emits (the reference's own order is hash-map
+// iteration order, src/pairwise.cpp:253) — by one device radix sort over the significant key bits
+static int sort_edges_device(ksp_edge* d_edges, u64 n, u32 n_sources) {
+    if (n < 2) return KSP_OK;
+    Buf k0, k1, v0, v1, tmp;
     int rc = KSP_OK;
     do {
-        // Tile ranges as large as possible: start with everything; when the edge buffer overflows, grow it
-        // to the reported count if memory allows, otherwise halve the range (sparse inputs need one launch,
-        // dense ones are cut into ranges whose non-zero pairs fit).
-        const u64 T = ksp_engine_num_tiles(e);
-        u64 cap = std::min<u64>(1ull << 24, ksp_engine_edge_bound(e, 0, T) + 1);   // at most 256 MiB to begin with
-        if ((rc = ksp_device_malloc(device, cap * sizeof(ksp_edge), &d_edges))) break;
-        size_t free_b = 0, total_b = 0;
-        (void)hipMemGetInfo(&free_b, &total_b);
-        const u64 max_cap = std::max<u64>(cap, (u64)(free_b / 2) / sizeof(ksp_edge));
-        u64 t = 0;
-        u64 step = std::max<u64>(T, 1);
-        ksp_stats acc{};
-        while (t < T && !rc) {
-            u64 t1 = std::min(T, t + step);
-            u64 cnt = 0;
-            rc = ksp_engine_join(e, t, t1, (ksp_edge*)d_edges, cap, &cnt, nullptr);
-            if (rc == KSP_E_OVERFLOW) {
-                rc = KSP_OK;
-                acc.ms_join += e->st.ms_join;
-                if (cnt <= max_cap) {
-                    (void)hipFree(d_edges);
-                    d_edges = nullptr;
-                    cap = std::min<u64>(max_cap, cnt + cnt / 16 + 1024);
-                    if ((rc = ksp_device_malloc(device, cap * sizeof(ksp_edge), &d_edges))) break;
-                } else if (t1 - t > 1) {
-                    step = (t1 - t) / 2;
-                } else {
-                    set_error("pairwise_host: a single tile yields more edges than fit in device memory");
-                    rc = KSP_E_LIMIT;
-                }
-                continue;
-            }
-            if (rc) break;
-            size_t old = all.size();
-            all.resize(old + cnt);
-            if (cnt) rc = ksp_memcpy_d2h(all.data() + old, d_edges, cnt * sizeof(ksp_edge));
-            acc.ms_join += e->st.ms_join;
-            acc.last_tiles += e->st.last_tiles;
-            acc.last_pairs += e->st.last_pairs;
-            t = t1;
-        }
+        if ((rc = k0.ensure(n * 8)) || (rc = k1.ensure(n * 8)) || (rc = v0.ensure(n * 8)) || (rc = v1.ensure(n * 8))) break;
+        const unsigned grid = (unsigned)std::min<u64>((n + 255) / 256, 1u << 20);
+        hipLaunchKernelGGL(k_edge_split, dim3(grid), dim3(256), 0, nullptr, d_edges, n, k0.as<u64>(), v0.as<u64>());
+        int sbits = 1;
+        while (sbits < 32 && (n_sources >> sbits)) ++sbits;
+        size_t tb = 0;
+        hipError_t err = rocprim::radix_sort_pairs(nullptr, tb, k0.as<u64>(), k1.as<u64>(), v0.as<u64>(), v1.as<u64>(), (size_t)n, 0, 32 + sbits, (hipStream_t) nullptr);
+        if (err == hipSuccess && !(rc = tmp.ensure(tb)))
+            err = rocprim::radix_sort_pairs(tmp.p, tb, k0.as<u64>(), k1.as<u64>(), v0.as<u64>(), v1.as<u64>(), (size_t)n, 0, 32 + sbits, (hipStream_t) nullptr);
         if (rc) break;
-        std::sort(all.begin(), all.end(), [](const ksp_edge& x, const ksp_edge& y) {
-            return x.source_1 != y.source_1 ? x.source_1 < y.source_1 : x.source_2 < y.source_2;
-        });
-        if (stats) {
-            ksp_engine_get_stats(e, stats);
-            stats->ms_join = acc.ms_join;
-            stats->last_tiles = acc.last_tiles;
-            stats->last_pairs = acc.last_pairs;
-            stats->last_edges = all.size();
-        }
-        ksp_edge* out = (ksp_edge*)std::malloc(std::max<size_t>(1, all.size()) * sizeof(ksp_edge));
-        if (!out) { set_error("pairwise_host: out of host memory"); rc = KSP_E_ARG; break; }
-        if (!all.empty()) std::memcpy(out, all.data(), all.size() * sizeof(ksp_edge));
-        *out_edges = out;
-        *n_edges = all.size();
+        if (err != hipSuccess) { set_error(std::string("sort_edges: ") + hipGetErrorString(err)); rc = KSP_E_HIP; break; }
+        hipLaunchKernelGGL(k_edge_merge, dim3(grid), dim3(256), 0, nullptr, k1.as<u64>(), v1.as<u64>(), n, d_edges);
+        err = hipDeviceSynchronize();
+        if (err != hipSuccess) { set_error(std::string("sort_edges: ") + hipGetErrorString(err)); rc = KSP_E_HIP; }
     } while (0);
-    if (d_edges) (void)hipFree(d_edges);
+    k0.release(); k1.release(); v0.release(); v1.release(); tmp.release();
     return rc;
+}
+
+namespace {
+// a plain barrier for the per-device host threads (C++17: no std::barrier)
+struct HostBarrier {
+    std::mutex mu;
+    std::condition_variable cv;
+    int n, waiting = 0;
+    unsigned gen = 0;
+    explicit HostBarrier(int n_) : n(n_) {}
+    void wait() {
+        std::unique_lock<std::mutex> l(mu);
+        const unsigned g = gen;
+        if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
+        else cv.wait(l, [&] { return gen != g; });
+    }
+};
+
+struct MultiJob {
+    // input (host): sketches (keys / weights / offsets) or an inverted index (key_off / sources / key_weights)
+    const u64* keys = nullptr; const u32* weights = nullptr; const u64* offsets = nullptr;
+    const u64* key_off = nullptr; const u32* sources = nullptr; const u32* key_weights = nullptr;
+    u32 n_keys = 0, n_sources = 0;
+    bool postings = false;
+};
+}  // namespace
+
+// The whole job on `nd` devices, one host thread + one engine per device (the reference entry points call this
+// with the devices of $KSPIDER_DEVICES; nd = 1 is the single-GPU path):
+//   stage 1   postings input: every device builds the same lists (that build is deterministic: ranks are the
+//             caller's key order).  Sketch input: device i builds the slice of its 1/nd share of the hash range;
+//             the labels are MIN-combined and the slices exchanged device to device (peer copies over xGMI),
+//             then every device assembles the full lists — the same exchange kspider_amd/dist.py does with
+//             RCCL collectives between processes.
+//   stage 2   device i joins the tile range [cuts[i], cuts[i+1]) of equal estimated work (same cuts everywhere:
+//             checked), the edges are gathered to the first device (peer copies), sorted there and copied into
+//             pinned host memory.
+static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats) {
+    *out_edges = nullptr;
+    *n_edges = 0;
+    if (nd < 1 || nd > 64) { set_error("pairwise: between 1 and 64 devices"); return KSP_E_ARG; }
+    const u32 N = job.n_sources;
+    const u64 n = job.postings ? (job.n_keys ? job.key_off[job.n_keys] : 0) : (N ? job.offsets[N] : 0);
+    struct Dev {
+        ksp_engine* e = nullptr;
+        void *d_a = nullptr, *d_b = nullptr;      // keys + weights, or sources + key weights
+        Buf edges, labels, gather[6], exp[6];
+        u64 count = 0, sizes[4] = {0, 0, 0, 0};
+        std::vector<u64> cuts;
+        float ms_join = 0;
+        int rc = KSP_OK;
+        std::string err;
+    };
+    std::vector<Dev> dev((size_t)nd);
+    HostBarrier bar(nd);
+    std::atomic<int> failed{0};
+    std::vector<u32> lab_min;                 // MIN-combined labels (host)
+    std::vector<std::vector<u32>> lab_dev((size_t)nd);
+    std::vector<u64> all_sizes((size_t)nd * 4, 0);
+    u64 total = 0;
+    std::vector<u64> edge_off((size_t)nd + 1, 0);
+    Buf merged;                               // all edges on the first device (nd > 1)
+
+    auto body = [&](int i) {
+        Dev& D = dev[(size_t)i];
+        const int device = devices[i];
+        auto fail = [&](int rc) { D.rc = rc; D.err = g_error; failed.store(1); };
+        auto sync_point = [&]() { bar.wait(); return failed.load() != 0; };
+        int rc = ksp_engine_create(device, &D.e);
+        if (rc) fail(rc);
+        for (int j = 0; j < nd && !rc; ++j)   // direct xGMI copies between the devices of this job (already enabled: fine)
+            if (devices[j] != device) { (void)hipDeviceEnablePeerAccess(devices[j], 0); (void)hipGetLastError(); }
+        // ---- stage 1 --------------------------------------------------------------------------------------------
+        if (!failed.load() && n) {
+            if (job.postings) {
+                if ((rc = ksp_device_malloc(device, n * 4, &D.d_a)) || (rc = ksp_memcpy_h2d(D.d_a, job.sources, n * 4))) fail(rc);
+                if (!rc && job.key_weights &&
+                    ((rc = ksp_device_malloc(device, (u64)job.n_keys * 4, &D.d_b)) || (rc = ksp_memcpy_h2d(D.d_b, job.key_weights, (u64)job.n_keys * 4))))
+                    fail(rc);
+            } else {
+                if ((rc = ksp_device_malloc(device, n * 8, &D.d_a)) || (rc = ksp_memcpy_h2d(D.d_a, job.keys, n * 8))) fail(rc);
+                if (!rc && job.weights && ((rc = ksp_device_malloc(device, n * 4, &D.d_b)) || (rc = ksp_memcpy_h2d(D.d_b, job.weights, n * 4))))
+                    fail(rc);
+            }
+        }
+        if (!failed.load()) {
+            if (job.postings)
+                rc = ksp_engine_build_postings(D.e, job.key_off, (const u32*)D.d_a, (const u32*)D.d_b, job.n_keys, N, nullptr);
+            else if (nd == 1)
+                rc = ksp_engine_build_blocks(D.e, (const u64*)D.d_a, (const u32*)D.d_b, job.offsets, N, 0, nullptr);
+            else
+                rc = ksp_engine_build_slice(D.e, (const u64*)D.d_a, (const u32*)D.d_b, job.offsets, N, 0, (u32)i, (u32)nd, nullptr);
+            if (rc) fail(rc);
+        }
+        if (!job.postings && nd > 1) {   // the slices become the full lists on every device
+            // common source order: element-wise MIN of the devices' labels
+            if (!failed.load() && N) {
+                lab_dev[(size_t)i].resize(N);
+                if ((rc = D.labels.ensure((size_t)N * 4)) || (rc = ksp_engine_slice_labels(D.e, D.labels.as<u32>(), nullptr)) ||
+                    (rc = ksp_memcpy_d2h(lab_dev[(size_t)i].data(), D.labels.p, (u64)N * 4)))
+                    fail(rc);
+            }
+            if (sync_point()) return;
+            if (i == 0) {
+                lab_min = lab_dev[0];
+                for (int j = 1; j < nd; ++j)
+                    for (u32 s = 0; s < N; ++s) lab_min[s] = std::min(lab_min[s], lab_dev[(size_t)j][s]);
+            }
+            if (sync_point()) return;
+            if (N && ((rc = ksp_memcpy_h2d(D.labels.p, lab_min.data(), (u64)N * 4)) || (rc = ksp_engine_slice_finish(D.e, D.labels.as<u32>(), nullptr))))
+                fail(rc);
+            else if (!N && (rc = ksp_engine_slice_finish(D.e, nullptr, nullptr)))
+                fail(rc);
+            if (!failed.load() && (rc = ksp_engine_slice_sizes(D.e, D.sizes))) fail(rc);
+            for (int q = 0; q < 4; ++q) all_sizes[(size_t)i * 4 + q] = D.sizes[q];
+            if (sync_point()) return;
+            // every device receives every slice: [part][stride] buffers, filled by peer copies from the owners
+            u64 lstride = 4, bigstride = 1;
+            for (int j = 0; j < nd; ++j) { lstride = std::max(lstride, all_sizes[(size_t)j * 4]); bigstride = std::max(bigstride, all_sizes[(size_t)j * 4 + 2]); }
+            const u32 nb = (N + TB - 1) / TB;
+            const bool weighted = job.weights != nullptr;
+            const size_t bytes[6] = {lstride * 4, lstride * 4, weighted ? lstride * 4 : 0, ((size_t)nb + 1) * 4, ((size_t)nb + 1) * 4, bigstride * 16};
+            for (int q = 0; q < 6 && !rc; ++q) {
+                if (!bytes[q]) continue;
+                if ((rc = D.exp[q].ensure(bytes[q])) || (rc = D.gather[q].ensure(bytes[q] * (size_t)nd))) fail(rc);
+                else if (hipMemset(D.exp[q].p, 0, bytes[q]) != hipSuccess || hipMemset(D.gather[q].p, 0, bytes[q] * (size_t)nd) != hipSuccess) { set_error("pairwise: hipMemset"); fail(rc = KSP_E_HIP); }
+            }
+            if (!failed.load() && n &&
+                (rc = ksp_engine_slice_export(D.e, D.exp[0].as<u32>(), D.exp[1].as<u32>(), weighted ? D.exp[2].as<u32>() : nullptr,
+                                              D.exp[3].as<u32>(), D.exp[4].as<u32>(), D.exp[5].p, nullptr)))
+                fail(rc);
+            if (sync_point()) return;
+            for (int j = 0; j < nd && !failed.load(); ++j)      // my slice into device j's gather buffers
+                for (int q = 0; q < 6; ++q) {
+                    if (!bytes[q]) continue;
+                    if (hipMemcpyPeer((char*)dev[(size_t)j].gather[q].p + bytes[q] * (size_t)i, devices[j], D.exp[q].p, device, bytes[q]) != hipSuccess) {
+                        set_error("pairwise: peer copy of a block-list slice failed");
+                        fail(KSP_E_HIP);
+                        break;
+                    }
+                }
+            if (sync_point()) return;
+            if ((rc = ksp_engine_assemble(D.e, (u32)nd, all_sizes.data(), D.gather[0].as<u32>(), D.gather[1].as<u32>(),
+                                          weighted ? D.gather[2].as<u32>() : nullptr, lstride, D.gather[3].as<u32>(), D.gather[4].as<u32>(),
+                                          D.gather[5].p, bigstride, nullptr)))
+                fail(rc);
+        }
+        if (sync_point()) return;
+        // ---- stage 2: my share of the tiles ------------------------------------------------------------------
+        D.cuts.assign((size_t)nd + 1, 0);
+        if ((rc = ksp_engine_balanced_cuts(D.e, (u32)nd, D.cuts.data()))) fail(rc);
+        if (sync_point()) return;
+        if (i == 0)
+            for (int j = 1; j < nd; ++j)
+                if (dev[(size_t)j].cuts != dev[0].cuts || dev[(size_t)j].e->st.n_block_keys != dev[0].e->st.n_block_keys) {
+                    set_error("pairwise: the devices built different block lists (cannot shard the tiles)");
+                    fail(KSP_E_HIP);
+                }
+        if (sync_point()) return;
+        if ((rc = join_range_grow(D.e, D.cuts[(size_t)i], D.cuts[(size_t)i + 1], D.edges, D.count, D.ms_join))) fail(rc);
+        if (sync_point()) return;
+        if (i == 0) {
+            for (int j = 0; j < nd; ++j) edge_off[(size_t)j + 1] = edge_off[(size_t)j] + dev[(size_t)j].count;
+            total = edge_off[(size_t)nd];
+            if (nd > 1 && total && (rc = merged.ensure(total * sizeof(ksp_edge)))) fail(rc);
+        }
+        if (sync_point()) return;
+        if (nd > 1 && D.count &&      // the gather to the first device: one peer copy per device (xGMI)
+            hipMemcpyPeer((char*)merged.p + edge_off[(size_t)i] * sizeof(ksp_edge), devices[0], D.edges.p, device, D.count * sizeof(ksp_edge)) != hipSuccess) {
+            set_error("pairwise: peer copy of the edges failed");
+            fail(KSP_E_HIP);
+        }
+        if (sync_point()) return;
+        if (i == 0) {
+            ksp_edge* d_all = nd > 1 ? merged.as<ksp_edge>() : D.edges.as<ksp_edge>();
+            if (total && (rc = sort_edges_device(d_all, total, N))) { fail(rc); return; }
+            ksp_edge* out = (ksp_edge*)alloc_result(total * sizeof(ksp_edge));
+            if (!out) { set_error("pairwise_host: out of pinned host memory"); fail(KSP_E_LIMIT); return; }
+            if (total && (rc = ksp_memcpy_d2h(out, d_all, total * sizeof(ksp_edge)))) { ksp_free(out); fail(rc); return; }
+            *out_edges = out;
+            *n_edges = total;
+            if (stats) {
+                ksp_engine_get_stats(D.e, stats);
+                stats->ms_join = 0; stats->last_tiles = 0; stats->last_pairs = 0;
+                for (int j = 0; j < nd; ++j) {
+                    stats->ms_join = std::max(stats->ms_join, dev[(size_t)j].ms_join);
+                    stats->last_tiles += dev[(size_t)j].e->st.last_tiles;
+                    stats->last_pairs += dev[(size_t)j].e->st.last_pairs;
+                }
+                stats->last_edges = total;
+            }
+        }
+    };
+    if (nd == 1) body(0);
+    else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < nd; ++i) th.emplace_back(body, i);
+        for (auto& t : th) t.join();
+    }
+    int rc = KSP_OK;
+    for (int i = 0; i < nd; ++i) {
+        Dev& D = dev[(size_t)i];
+        if (D.rc && !rc) { rc = D.rc; set_error(D.err); }
+        if (D.e) (void)hipSetDevice(D.e->device);
+        if (D.d_a) (void)hipFree(D.d_a);
+        if (D.d_b) (void)hipFree(D.d_b);
+        D.edges.release(); D.labels.release();
+        for (int q = 0; q < 6; ++q) { D.gather[q].release(); D.exp[q].release(); }
+        ksp_engine_destroy(D.e);
+    }
+    if (nd > 1 || merged.p) { (void)hipSetDevice(devices[0]); merged.release(); }
+    if (rc && *out_edges) { ksp_free(*out_edges); *out_edges = nullptr; *n_edges = 0; }
+    return rc;
+}
+
+int ksp_pairwise_host_multi(const uint64_t* keys, const uint32_t* weights, const uint64_t* offsets, uint32_t n_sources,
+                            const int* devices, int n_devices, ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats) {
+    if (!offsets || !out_edges || !n_edges || !devices) { set_error("pairwise_host: NULL argument"); return KSP_E_ARG; }
+    MultiJob job;
+    job.keys = keys; job.weights = weights; job.offsets = offsets; job.n_sources = n_sources;
+    return run_multi(job, devices, n_devices, out_edges, n_edges, stats);
+}
+
+int ksp_pairwise_postings_host_multi(const uint64_t* key_off, const uint32_t* sources, const uint32_t* key_weights,
+                                     uint32_t n_keys, uint32_t n_sources, const int* devices, int n_devices,
+                                     ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats) {
+    if (!out_edges || !n_edges || !devices || (n_keys && (!key_off || !sources))) { set_error("pairwise_postings_host: NULL argument"); return KSP_E_ARG; }
+    const u64 n = n_keys ? key_off[n_keys] : 0;
+    for (u64 i = 0; i < n; ++i)
+        if (sources[i] >= n_sources) { set_error("pairwise_postings_host: source index out of range"); return KSP_E_ARG; }
+    MultiJob job;
+    job.postings = true;
+    job.key_off = key_off; job.sources = sources; job.key_weights = key_weights; job.n_keys = n_keys; job.n_sources = n_sources;
+    return run_multi(job, devices, n_devices, out_edges, n_edges, stats);
 }
 
 int ksp_pairwise_host(const uint64_t* keys, const uint32_t* weights, const uint64_t* offsets, uint32_t n_sources,
                       int device, ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats) {
-    if (!offsets || !out_edges || !n_edges) { set_error("pairwise_host: NULL argument"); return KSP_E_ARG; }
-    *out_edges = nullptr;
-    *n_edges = 0;
-    ksp_engine* e = nullptr;
-    int rc = ksp_engine_create(device, &e);
-    if (rc) return rc;
-    const u64 n = n_sources ? offsets[n_sources] : 0;
-    void *d_keys = nullptr, *d_w = nullptr;
-    do {
-        if (n) {
-            if ((rc = ksp_device_malloc(device, n * 8, &d_keys))) break;
-            if ((rc = ksp_memcpy_h2d(d_keys, keys, n * 8))) break;
-            if (weights) {
-                if ((rc = ksp_device_malloc(device, n * 4, &d_w))) break;
-                if ((rc = ksp_memcpy_h2d(d_w, weights, n * 4))) break;
-            }
-        }
-        if ((rc = ksp_engine_build_blocks(e, (const u64*)d_keys, (const u32*)d_w, offsets, n_sources, 0, nullptr))) break;
-        rc = collect_all_edges(e, device, out_edges, n_edges, stats);
-    } while (0);
-    if (d_keys) (void)hipFree(d_keys);
-    if (d_w) (void)hipFree(d_w);
-    ksp_engine_destroy(e);
-    return rc;
+    return ksp_pairwise_host_multi(keys, weights, offsets, n_sources, &device, 1, out_edges, n_edges, stats);
 }
 
 int ksp_pairwise_postings_host(const uint64_t* key_off, const uint32_t* sources, const uint32_t* key_weights,
                                uint32_t n_keys, uint32_t n_sources, int device, ksp_edge** out_edges,
                                uint64_t* n_edges, ksp_stats* stats) {
-    if (!out_edges || !n_edges || (n_keys && (!key_off || !sources))) { set_error("pairwise_postings_host: NULL argument"); return KSP_E_ARG; }
-    *out_edges = nullptr;
-    *n_edges = 0;
-    ksp_engine* e = nullptr;
-    int rc = ksp_engine_create(device, &e);
-    if (rc) return rc;
-    const u64 n = n_keys ? key_off[n_keys] : 0;
-    for (u64 i = 0; i < n; ++i)
-        if (sources[i] >= n_sources) { set_error("pairwise_postings_host: source index out of range"); ksp_engine_destroy(e); return KSP_E_ARG; }
-    void *d_src = nullptr, *d_w = nullptr;
-    do {
-        if (n) {
-            if ((rc = ksp_device_malloc(device, n * 4, &d_src))) break;
-            if ((rc = ksp_memcpy_h2d(d_src, sources, n * 4))) break;
-            if (key_weights) {
-                if ((rc = ksp_device_malloc(device, (u64)n_keys * 4, &d_w))) break;
-                if ((rc = ksp_memcpy_h2d(d_w, key_weights, (u64)n_keys * 4))) break;
-            }
-        }
-        if ((rc = ksp_engine_build_postings(e, key_off, (const u32*)d_src, (const u32*)d_w, n_keys, n_sources, nullptr))) break;
-        rc = collect_all_edges(e, device, out_edges, n_edges, stats);
-    } while (0);
-    if (d_src) (void)hipFree(d_src);
-    if (d_w) (void)hipFree(d_w);
-    ksp_engine_destroy(e);
-    return rc;
+    return ksp_pairwise_postings_host_multi(key_off, sources, key_weights, n_keys, n_sources, &device, 1, out_edges, n_edges, stats);
 }
 
 }  // extern "C"

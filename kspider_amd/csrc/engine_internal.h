@@ -7,8 +7,12 @@
 
 #include "../../include/kspider_amd.h"
 
+#include <vector>
+
 namespace ksp {
 void set_error(const std::string& s);
+// GPUs of a drop-in call: $KSPIDER_DEVICES ("0,1,2,..."; a device may appear twice) or the one of $KSPIDER_DEVICE (0)
+std::vector<int> devices_from_env();
 }
 
 extern "C" {

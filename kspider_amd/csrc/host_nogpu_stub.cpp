@@ -16,12 +16,13 @@ void set_error(const std::string& s) { g_error = s; }
 extern "C" {
 const char* ksp_last_error(void) { return ksp::g_error.c_str(); }
 void ksp_free(void* p) { std::free(p); }
-int ksp_pairwise_host(const uint64_t*, const uint32_t*, const uint64_t*, uint32_t, int, ksp_edge**, uint64_t*, ksp_stats*) {
+int ksp_pairwise_host_multi(const uint64_t*, const uint32_t*, const uint64_t*, uint32_t, const int*, int, ksp_edge**,
+                            uint64_t*, ksp_stats*) {
     ksp::set_error("host-only sanitizer build: no HIP engine");
     return KSP_E_HIP;
 }
-int ksp_pairwise_postings_host(const uint64_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, int, ksp_edge**,
-                               uint64_t*, ksp_stats*) {
+int ksp_pairwise_postings_host_multi(const uint64_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, const int*, int,
+                                     ksp_edge**, uint64_t*, ksp_stats*) {
     ksp::set_error("host-only sanitizer build: no HIP engine");
     return KSP_E_HIP;
 }

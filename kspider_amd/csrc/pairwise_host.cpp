@@ -23,6 +23,29 @@
 #include "engine_internal.h"
 #include "index_io.h"
 
+namespace ksp {
+std::vector<int> devices_from_env() {
+    std::vector<int> out;
+    if (const char* ds = std::getenv("KSPIDER_DEVICES")) {
+        const char* p = ds;
+        while (*p) {
+            char* end = nullptr;
+            const long v = std::strtol(p, &end, 10);
+            if (end == p) break;
+            out.push_back((int)v);
+            p = *end == ',' ? end + 1 : end;
+            if (*end && *end != ',') break;
+        }
+    }
+    if (out.empty()) {
+        int device = 0;
+        if (const char* d = std::getenv("KSPIDER_DEVICE")) device = std::atoi(d);
+        out.push_back(device);
+    }
+    return out;
+}
+}  // namespace ksp
+
 namespace {
 
 typedef std::chrono::high_resolution_clock Clock;
@@ -113,14 +136,13 @@ int run_pairwise(const std::string& prefix, int user_threads) {
     //  were resolved by load_index the way insert_or_assign does)
 
     const double t_transpose = since(t0);
-    int device = 0;
-    if (const char* d = std::getenv("KSPIDER_DEVICE")) device = std::atoi(d);
+    const std::vector<int> devices = ksp::devices_from_env();
     ksp_edge* edges = nullptr;
     uint64_t n_edges = 0;
     ksp_stats st;
     auto t1 = Clock::now();
-    int rc = ksp_pairwise_postings_host(key_off.data(), post_src.data(), key_w.data(), (uint32_t)key_w.size(), N, device,
-                                        &edges, &n_edges, &st);
+    int rc = ksp_pairwise_postings_host_multi(key_off.data(), post_src.data(), key_w.data(), (uint32_t)key_w.size(), N,
+                                              devices.data(), (int)devices.size(), &edges, &n_edges, &st);
     const double t_device = since(t1);
     if (rc != KSP_OK) return rc;
     std::vector<ksp::EdgeRow> rows;

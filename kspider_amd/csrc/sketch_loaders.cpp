@@ -247,11 +247,11 @@ int run_sources(const std::string& prefix, const std::vector<std::pair<uint32_t,
     for (size_t i = 0; i < src.size(); ++i) offsets[i + 1] = offsets[i] + src[i].run.size();
     std::vector<uint64_t> keys(offsets.back());
     for (size_t i = 0; i < src.size(); ++i) std::copy(src[i].run.begin(), src[i].run.end(), keys.begin() + offsets[i]);
-    int device = 0;
-    if (const char* d = std::getenv("KSPIDER_DEVICE")) device = std::atoi(d);
+    const std::vector<int> devices = ksp::devices_from_env();
     ksp_edge* edges = nullptr;
     uint64_t n_edges = 0;
-    int rc = ksp_pairwise_host(keys.data(), nullptr, offsets.data(), (uint32_t)src.size(), device, &edges, &n_edges, nullptr);
+    int rc = ksp_pairwise_host_multi(keys.data(), nullptr, offsets.data(), (uint32_t)src.size(), devices.data(),
+                                     (int)devices.size(), &edges, &n_edges, nullptr);
     if (rc != KSP_OK) return rc;
     std::vector<ksp::EdgeRow> rows;
     rows.reserve(n_edges);

@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "ksp_engine_edge_bound", "ksp_engine_slice_labels", "ksp_engine_slice_finish", "ksp_engine_balanced_cuts",
     "ksp_engine_build_postings", "ksp_pairwise_postings_host",
     "ksp_engine_set_profiling", "ksp_engine_phase_times",
+    "ksp_pairwise_host_multi", "ksp_pairwise_postings_host_multi",
 ]
 
 
@@ -98,6 +99,13 @@ def lib():
                                         ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
                                         ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(Stats)]
         L.ksp_free.argtypes = [ctypes.c_void_p]
+        L.ksp_pairwise_host_multi.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                              ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p),
+                                              ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(Stats)]
+        L.ksp_pairwise_postings_host_multi.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                                       ctypes.c_uint32, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                                       ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64),
+                                                       ctypes.POINTER(Stats)]
         L.ksp_engine_build_postings.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p]
         L.ksp_pairwise_postings_host.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
@@ -127,8 +135,10 @@ def device_count() -> int:
     return n.value
 
 
-def pairwise_host(keys: np.ndarray, offsets: np.ndarray, weights: np.ndarray | None = None, device: int = 0):
-    """Host sketches -> (edges sorted by (source_1, source_2), stats).  IDs are dense 0..N-1."""
+def pairwise_host(keys: np.ndarray, offsets: np.ndarray, weights: np.ndarray | None = None, device: int = 0,
+                  devices: list | None = None):
+    """Host sketches -> (edges sorted by (source_1, source_2), stats).  IDs are dense 0..N-1.
+    `devices`: shard the job over several GPUs (ksp_pairwise_host_multi; a device may be named twice)."""
     keys = np.ascontiguousarray(keys, dtype=np.uint64)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     w = None if weights is None else np.ascontiguousarray(weights, dtype=np.uint32)
@@ -136,8 +146,9 @@ def pairwise_host(keys: np.ndarray, offsets: np.ndarray, weights: np.ndarray | N
     out = ctypes.c_void_p()
     ne = ctypes.c_uint64(0)
     st = Stats()
-    _check(lib().ksp_pairwise_host(keys.ctypes.data, w.ctypes.data if w is not None else None, offsets.ctypes.data,
-                                   n, device, ctypes.byref(out), ctypes.byref(ne), ctypes.byref(st)))
+    devs = (ctypes.c_int * len(devices))(*devices) if devices else (ctypes.c_int * 1)(device)
+    _check(lib().ksp_pairwise_host_multi(keys.ctypes.data, w.ctypes.data if w is not None else None, offsets.ctypes.data,
+                                         n, devs, len(devs), ctypes.byref(out), ctypes.byref(ne), ctypes.byref(st)))
     try:
         buf = (ctypes.c_char * (ne.value * EDGE_DTYPE.itemsize)).from_address(out.value) if ne.value else b""
         edges = np.frombuffer(buf, dtype=EDGE_DTYPE).copy()
@@ -164,7 +175,7 @@ def pairwise_bins(bins_dir: str, out_prefix: str | None = None, user_threads: in
 
 
 def pairwise_postings_host(key_off: np.ndarray, sources: np.ndarray, key_weights: np.ndarray | None, n_sources: int,
-                           device: int = 0):
+                           device: int = 0, devices: list | None = None):
     """Inverted index (key k held by sources[key_off[k]:key_off[k+1]], weight key_weights[k] or 1) ->
     (edges sorted by (source_1, source_2), stats).  What the drop-in path feeds the engine."""
     key_off = np.ascontiguousarray(key_off, dtype=np.uint64)
@@ -173,9 +184,10 @@ def pairwise_postings_host(key_off: np.ndarray, sources: np.ndarray, key_weights
     out = ctypes.c_void_p()
     n = ctypes.c_uint64(0)
     st = Stats()
-    _check(lib().ksp_pairwise_postings_host(key_off.ctypes.data, sources.ctypes.data, kw.ctypes.data if kw is not None else None,
-                                            key_off.size - 1, n_sources, device, ctypes.byref(out), ctypes.byref(n),
-                                            ctypes.byref(st)))
+    devs = (ctypes.c_int * len(devices))(*devices) if devices else (ctypes.c_int * 1)(device)
+    _check(lib().ksp_pairwise_postings_host_multi(key_off.ctypes.data, sources.ctypes.data,
+                                                  kw.ctypes.data if kw is not None else None, key_off.size - 1, n_sources,
+                                                  devs, len(devs), ctypes.byref(out), ctypes.byref(n), ctypes.byref(st)))
     try:
         buf = (ctypes.c_char * (n.value * EDGE_DTYPE.itemsize)).from_address(out.value) if n.value else b""
         edges = np.frombuffer(buf, dtype=EDGE_DTYPE).copy()
