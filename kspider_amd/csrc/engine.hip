@@ -115,6 +115,7 @@ struct ksp_engine {
     bool use_cells = true;        // rank-aligned cell join (KSP_JOIN=window selects the sliding-window merge)
     bool full_sort = false;       // keys defeat the 32-bit prefix sort: use all bits
     bool hash_off = false;        // keys defeat the bucket grouping (a bucket overflowed): use the sort path
+    bool pre_zeroed_work = false, pre_zeroed_bits = false;   // dwork / tbits were zeroed by the build's one zeroing launch
     bool part_off = false;        // the hand-written partition gave up on these keys (page tables full): rocPRIM partition
     u32 part_min = 4096;          // entries from which the hand-written partition is used (KSP_PART_MIN)
     ksp::Buf PK, PT, PD, parena;  // level-1 pages of the partition: keys, tags, digit bytes; pools, cursors, page tables
@@ -150,6 +151,10 @@ struct ksp_engine {
     ksp::Buf tbits, dwork, d_act, d_wg;
     unsigned char* h_stage = nullptr;   // pinned: diagonal work + overflow flag, then the tile bitmap
     size_t h_stage_bytes = 0;
+    unsigned char* h_blk_stage = nullptr;   // pinned: per-block maxima, then the list offsets (stage_block_tables)
+    size_t h_blk_stage_bytes = 0;
+    bool blk_staged = false;
+    bool d_off_sketch = false;          // d_off holds the sketch offsets of h_off (an unchanged set is not uploaded again)
     std::vector<u32> wg_host;           // share -> active tile (kept alive for the asynchronous upload)
     unsigned long long* h_count = nullptr;   // pinned
     u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
@@ -201,6 +206,24 @@ static u32 label_sampling(const ksp_engine* e, u64 kept_entries) {
     u32 every = 1;
     while (every < 64 && small / (2 * every) >= 64) every *= 2;
     return every - 1;
+}
+
+// several small regions zeroed by ONE launch (a build used to issue ~10 runtime fills of a few bytes to a few
+// hundred KB each; every one of them is a dispatch of its own)
+struct ZeroList {
+    u32* p[8];
+    u32 words[8];
+    int n;
+};
+__global__ void k_zero_regions(const ZeroList z) {
+    for (int r = 0; r < z.n; ++r)
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < z.words[r]; i += gridDim.x * blockDim.x) z.p[r][i] = 0;
+}
+static inline void zero_add(ZeroList& z, void* p, size_t bytes) {
+    if (!bytes) return;
+    z.p[z.n] = (u32*)p;
+    z.words[z.n] = (u32)((bytes + 3) / 4);
+    ++z.n;
 }
 
 template <class V>
@@ -290,15 +313,54 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if (!W && phase == 0 && e->nparts == 1 && !e->hash_off && !e->full_sort && !e->part_off && n >= e->part_min) {
         u32 mean = HB_HAND_MEAN;
         if (const char* bm = std::getenv("KSP_DEBUG_BUCKET_MEAN")) mean = (u32)std::max(64, std::atoi(bm));   // (timing experiments)
-        const u64 want = (n + mean - 1) / mean;
+        u64 want = (n + mean - 1) / mean;
+        if (want > 65536 && (n + 65535) / 65536 <= HB_HAND_MEAN_MAX) want = 65536;   // (somewhat larger buckets rather than the library path)
         if (want <= 65536) nb_hand = (u32)std::max<u64>(1, want);
     }
     const bool hand = nb_hand > 0;
-    KSP_HIP(hipMemsetAsync(scal + 4, 0, 8 * 11, st));   // [4] .. [14]: overflow words, counters of the partition
+    e->pre_zeroed_work = e->pre_zeroed_bits = false;
+    // layout of the hand-written partition's arena (see the partition step below)
+    int hp_pb2 = 0;
+    u32 hp_nb1 = 0, hp_lists = 0, hp_ptw = 0, hp_pool_r = 0, hp_nchunks = 0;
+    size_t hp_pages = 0, hp_zero_words = 0;
     if (hand) {
+        while (((nb_hand + (1u << hp_pb2) - 1) >> hp_pb2) > 256) ++hp_pb2;
+        hp_nb1 = (nb_hand + (1u << hp_pb2) - 1) >> hp_pb2;
+        hp_lists = hp_nb1 * P1_R;
+        hp_ptw = (u32)std::min<u64>(P1_PTW_MAX, 16 * (((n / hp_lists) >> P1_PLOG) + 1) + 16);
+        const u64 per_r = n / P1_R;
+        hp_pool_r = (u32)((per_r >> P1_PLOG) + (per_r >> (P1_PLOG + 3)) + hp_nb1 + 8);   // pages per sub-list class
+        hp_pages = (size_t)hp_pool_r * P1_R;
+        hp_nchunks = grid_for(n, P1_CH);
+        // arena (zeroed per build): pools and cursors (one line each), page tables, page owners, bucket counters |
+        // chunk sources
+        hp_zero_words = (size_t)P1_R * P1_LINE + (size_t)hp_lists * P1_LINE + (size_t)hp_lists * hp_ptw + hp_pages +
+                        ((size_t)nb_hand + 1);
+        if ((rc = e->parena.ensure((hp_zero_words + hp_nchunks + 2) * 4))) return rc;
+        // everything this build needs zeroed, in one launch: the scalar block, the per-block maxima, the partition's
+        // arena, the bucket totals, and (small inputs) the diagonal work and the tile bitmap of the work list
+        ZeroList z{};
+        zero_add(z, scal, 128);
+        zero_add(z, e->blk_max.p, ((size_t)nb + 1) * 4);
+        zero_add(z, e->parena.p, hp_zero_words * 4);
+        zero_add(z, (u64*)e->KB.p + (n / 2 + 1), (size_t)nb_hand * 8);   // bsum (see the partition step)
+        if (nb <= KG_WORK) {
+            if ((rc = e->dwork.ensure(((size_t)nb + 2) * 8))) return rc;
+            zero_add(z, e->dwork.p, ((size_t)nb + 2) * 8);
+            e->pre_zeroed_work = true;
+        }
+        const u64 T = (u64)nb * (nb + 1) / 2;
+        if (T <= (1ull << 22)) {
+            const size_t bit_words = (size_t)(((T + 63) / 64) * 2 + 2);
+            if ((rc = e->tbits.ensure(bit_words * 4 + T + 64))) return rc;
+            zero_add(z, e->tbits.p, bit_words * 4 + T + 64);
+            e->pre_zeroed_bits = true;
+        }
         phase_mark(e, st, "key range + source sizes");
-        KSP_HIP(hipMemsetAsync(scal, 0, 8, st));
+        hipLaunchKernelGGL(k_zero_regions, dim3(256), dim3(256), 0, st, z);
         hipLaunchKernelGGL(k_max_last, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_keys, d_off, (unsigned long long*)scal, N);
+    } else {
+        KSP_HIP(hipMemsetAsync(scal + 4, 0, 8 * 11, st));   // [4] .. [14]: overflow words, counters of the partition
     }
     // key range (one 8-byte D2H, unless the caller passed key_bits)
     if (!hand && e->key_bits <= 0) {
@@ -319,7 +381,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         hipLaunchKernelGGL((k_tag<V, W>), dim3(N), dim3(256), 0, st, d_off, d_w, VA, sbound);
     if (!W) hipLaunchKernelGGL(k_src_size, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_off, sbound, N);
     hipLaunchKernelGGL(k_iota4, dim3(grid_for(N, bs)), dim3(bs), 0, st, iota, order, newidx, label, N);   // (order, newidx: identity until the labels are known)
-    KSP_HIP(hipMemsetAsync(e->blk_max.p, 0, ((size_t)nb + 1) * 4, st));
+    if (!hand) KSP_HIP(hipMemsetAsync(e->blk_max.p, 0, ((size_t)nb + 1) * 4, st));
     if (!reorder) hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
     // slice mode (multi-GPU build): keep only the entries of this part's key range — one contiguous
     // sub-run per (sorted) source, so the cost is proportional to the slice, not to the sketch set
@@ -396,22 +458,12 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         u32* d_hovf = (u32*)(scal + 9);
         if (hand) {
             // two-level partition by bucket = floor(key * nbuckets / (max key + 1)): d_keys -> pages -> KA, VB, bstart
-            int pb2 = 0;
-            while (((nbuckets + (1u << pb2) - 1) >> pb2) > 256) ++pb2;
-            const u32 nb1 = (nbuckets + (1u << pb2) - 1) >> pb2, lists = nb1 * P1_R;
-            const u32 ptw = (u32)std::min<u64>(P1_PTW_MAX, 16 * (((nw / lists) >> P1_PLOG) + 1) + 16);
-            const u64 per_r = nw / P1_R;
-            const u32 pool_r = (u32)((per_r >> P1_PLOG) + (per_r >> (P1_PLOG + 3)) + nb1 + 8);   // pages per sub-list class
-            const size_t pages = (size_t)pool_r * P1_R;
-            const u32 nchunks = grid_for(nw, P1_CH);
+            const int pb2 = hp_pb2;
+            const u32 nb1 = hp_nb1, lists = hp_lists, ptw = hp_ptw, pool_r = hp_pool_r, nchunks = hp_nchunks;
+            const size_t pages = hp_pages;
             if ((rc = e->PK.ensure(pages * P1_PAGE * 8))) return rc;
             if ((rc = e->PT.ensure(pages * P1_PAGE * sizeof(V)))) return rc;
             if ((rc = e->PD.ensure(pages * P1_PAGE))) return rc;
-            // arena (zeroed per build): pools and cursors (one line each), page tables, page owners, bucket counters |
-            // chunk sources
-            const size_t zero_words = (size_t)P1_R * P1_LINE + (size_t)lists * P1_LINE + (size_t)lists * ptw + pages +
-                                      ((size_t)nbuckets + 1);
-            if ((rc = e->parena.ensure((zero_words + nchunks + 2) * 4))) return rc;
             u32* pools = e->parena.as<u32>();
             u32* cursors = pools + (size_t)P1_R * P1_LINE;
             u32* ptab = cursors + (size_t)lists * P1_LINE;
@@ -420,7 +472,6 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             u32* src_tbl = gcur + ((size_t)nbuckets + 1);
             phase_mark(e, st, "partition");
             KSP_HIP(hipEventRecord(e->ev[4], st));
-            KSP_HIP(hipMemsetAsync(pools, 0, zero_words * 4, st));
             hipLaunchKernelGGL(k_part_src, dim3(grid_for((u64)nchunks + 1, bs)), dim3(bs), 0, st, d_off, N, nchunks, src_tbl,
                                scal, nbuckets);
             hipLaunchKernelGGL((k_part1<V>), dim3(nchunks), dim3(P1_THREADS), 0, st, d_keys, d_off, N, (u32)nw, scal, pb2,
@@ -431,8 +482,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             hipLaunchKernelGGL((k_scatter2<V>), dim3((u32)pages), dim3(P2_THREADS), 0, st, scal, cursors, owner, ptw, pb2,
                                nbuckets - 1, e->PK.as<u64>(), e->PT.as<V>(), gcur, KA, VB);
             KSP_HIP(hipEventRecord(e->ev[5], st));
-            phase_mark(e, st, "bucket grouping");
-            KSP_HIP(hipMemsetAsync(bsum, 0, (size_t)nbuckets * 8, st));
+            phase_mark(e, st, "bucket grouping");   // (bsum: zeroed with the rest at the start of the build)
         } else {
         phase_mark(e, st, "partition");
         KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, KA, tags_in, VB, nw, shiftb, topbit, st));
@@ -592,7 +642,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             unsigned long long* work = nullptr;
             if (nb <= KG_WORK && phase != 2) {
                 if ((rc = e->dwork.ensure(((size_t)nb + 2) * 8))) return rc;
-                KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
+                if (!e->pre_zeroed_work) KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
+                e->pre_zeroed_work = false;
                 work = e->dwork.as<unsigned long long>();
             }
             hipLaunchKernelGGL(k_move_groups, dim3(std::min<u32>(grid_for(U, bs), 512u)), dim3(bs), 0, st, gsum, goff, firstp,
@@ -699,7 +750,8 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     u32 *pr2 = ranked ? e->gp.as<u32>() + 3 * (K + 4) : (u32*)e->KB.p, *pb2 = ranked ? e->gp.as<u32>() + 2 * (K + 4) : pr2 + (K + 4);
     unsigned char* flags = (unsigned char*)e->tbits.p + bit_words * 4;
     phase_mark(e, st, "work list");
-    KSP_HIP(hipMemsetAsync(e->tbits.p, 0, bit_words * 4 + T + 64, st));
+    if (!e->pre_zeroed_bits) KSP_HIP(hipMemsetAsync(e->tbits.p, 0, bit_words * 4 + T + 64, st));
+    e->pre_zeroed_bits = false;
     if (!(ranked && e->have_dwork)) {
         KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
         const u32 shares = (u32)std::min<u64>(64, std::max<u64>(1, 2048 / nb));
@@ -783,6 +835,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
+    if (e->h_blk_stage) (void)hipHostFree(e->h_blk_stage);
     for (int i = 0; i < 6; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     for (int i = 0; i < ksp_engine::kMaxPhase; ++i) if (e->ph_ev[i]) (void)hipEventDestroy(e->ph_ev[i]);
     delete e;
@@ -883,8 +936,39 @@ static int build_schedule(ksp_engine* e) {
 }
 
 // host-side bookkeeping once the full block lists sit in the engine's arrays
+// per-block maxima and list offsets to pinned host memory, in stream order (before the build's last synchronisation:
+// finish_build then reads them without a copy of its own)
+static int stage_block_tables(ksp_engine* e, hipStream_t st) {
+    const size_t bytes = ((size_t)e->nb + 1) * 4;
+    if (e->h_blk_stage_bytes < 2 * bytes) {
+        if (e->h_blk_stage) (void)hipHostFree(e->h_blk_stage);
+        e->h_blk_stage = nullptr; e->h_blk_stage_bytes = 0;
+        KSP_HIP(hipHostMalloc((void**)&e->h_blk_stage, 2 * bytes + 4096));
+        e->h_blk_stage_bytes = 2 * bytes + 4096;
+    }
+    KSP_HIP(hipMemcpyAsync(e->h_blk_stage, e->blk_max.p, bytes, hipMemcpyDeviceToHost, st));
+    KSP_HIP(hipMemcpyAsync(e->h_blk_stage + bytes, e->blk_raw.p, bytes, hipMemcpyDeviceToHost, st));
+    e->blk_staged = true;
+    return KSP_OK;
+}
+
 static int finish_build(ksp_engine* e) {
     e->st.key_bits = e->key_bits;
+    if (e->blk_staged) {
+        const size_t bytes = ((size_t)e->nb + 1) * 4;
+        e->h_blk_off.resize((size_t)e->nb + 1);
+        std::memcpy(e->h_blk_max.data(), e->h_blk_stage, bytes);
+        std::memcpy(e->h_blk_off.data(), e->h_blk_stage + bytes, bytes);
+        e->blk_staged = false;
+        u32 big_blocks = 0;
+        for (u32 b = 0; b < e->nb; ++b) big_blocks += e->h_blk_max[b] >= 65536u;
+        e->need32 = big_blocks >= 1;
+        e->st.n_block_keys = e->h_blk_off[e->nb];
+        int rc = build_schedule(e);
+        if (rc) return rc;
+        e->built = true;
+        return KSP_OK;
+    }
     KSP_HIP(hipMemcpy(e->h_blk_max.data(), e->blk_max.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
     {
         u32 big_blocks = 0;
@@ -924,7 +1008,10 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     e->have_max_key = false;
     e->nparts = nparts;
     e->part_id = part;
-    e->h_off.assign(h_offsets, h_offsets + n_sources + 1);
+    const bool same_offsets = e->d_off_sketch && e->h_off.size() == (size_t)n_sources + 1 &&
+                              std::memcmp(e->h_off.data(), h_offsets, ((size_t)n_sources + 1) * 8) == 0;
+    if (!same_offsets) { e->h_off.assign(h_offsets, h_offsets + n_sources + 1); e->d_off_sketch = false; }
+    e->blk_staged = false;
     if (std::getenv("KSP_FULL_SORT")) e->full_sort = true;   // diagnostic: sort on all key bits
     if (const char* hg = std::getenv("KSP_HASH_GROUP")) e->hash_off = std::atoi(hg) == 0;   // diagnostic / tests
     if (const char* kg = std::getenv("KSP_KEY_GROUPS")) e->key_groups_off = std::atoi(kg) == 0;
@@ -946,7 +1033,10 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     int rc;
     if ((rc = e->d_off.ensure(((size_t)n_sources + 1) * 8))) return rc;
     KSP_HIP(hipEventRecord(e->ev[0], st));
-    KSP_HIP(hipMemcpyAsync(e->d_off.p, h_offsets, ((size_t)n_sources + 1) * 8, hipMemcpyHostToDevice, st));
+    if (!same_offsets) {   // (the engine's own copy is the source: the caller's array may go away before the copy has run)
+        KSP_HIP(hipMemcpyAsync(e->d_off.p, e->h_off.data(), ((size_t)n_sources + 1) * 8, hipMemcpyHostToDevice, st));
+        e->d_off_sketch = true;
+    }
     {   // fine cells: ~32 entries of the largest block per cell, power of two, index kept below 1 GiB
         u64 dmax = 0;
         for (u32 b = 0; b < e->nb; ++b) {
@@ -978,6 +1068,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
         e->h_scal_words = e->h_scal[1];
         e->h_scal_keys = e->h_scal[2];
         if ((rc = launch_sched_kernels(e, st))) return rc;
+        if ((rc = stage_block_tables(e, st))) return rc;
     }
     KSP_HIP(hipEventRecord(e->ev[1], st));
     KSP_HIP(hipStreamSynchronize(st));
@@ -1056,6 +1147,7 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
         KSP_HIP(hipMemcpyAsync(e->d_off.p, off32.data(), off32.size() * 4, hipMemcpyHostToDevice, st));
         KSP_HIP(hipStreamSynchronize(st));   // (off32 is a local)
     }
+    e->d_off_sketch = false;   // (d_off now holds the key offsets)
     e->post_off = e->d_off.as<u32>();
     e->post_src = d_sources;
     e->post_w = d_key_weights;
@@ -1274,10 +1366,13 @@ uint64_t ksp_engine_tile_pairs(const ksp_engine* e, uint64_t t0, uint64_t t1) {
         u64 row_end = tile_row_start((u64)I + 1, e->nb);
         u64 stop = std::min(row_end, t1);
         u64 nI = (I == e->nb - 1) ? last : TB;
-        for (u64 tt = t; tt < stop; ++tt) {
-            u32 JJ = J + (u32)(tt - t);
-            u64 nJ = (JJ == e->nb - 1) ? last : TB;
-            pairs += (JJ == I) ? nI * (nI - 1) / 2 : nI * nJ;
+        // tiles (I, J .. J + cnt - 1) in closed form: the diagonal one, full blocks, the (shorter) last block
+        u64 cnt = stop - t, J0 = J;
+        if (J0 == I) { pairs += nI * (nI - 1) / 2; ++J0; --cnt; }
+        if (cnt) {
+            const u64 J1 = J0 + cnt - 1;                     // last column of this piece
+            const u64 full = J1 == e->nb - 1 ? cnt - 1 : cnt;
+            pairs += nI * (full * TB + (J1 == e->nb - 1 ? last : 0));
         }
         t = stop;
     }
@@ -1453,16 +1548,14 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
             const u64 kI = e->h_blk_off[I + 1] - e->h_blk_off[I], kJ = e->h_blk_off[J + 1] - e->h_blk_off[J];
             bytes += (J == I) ? kI * (e->weighted ? 8 : 4) : (kI + kJ) * per;
         }
-        for (u64 t = tile_begin; !e->sched_on && t < tile_end;) {
+        for (u64 t = tile_begin; !e->sched_on && t < tile_end;) {   // dense mode, row by row in closed form (h_blk_off is a prefix sum)
             u32 I, J;
             tile_decode(t, e->nb, I, J);
             u64 stop = std::min(tile_row_start((u64)I + 1, e->nb), tile_end);
             u64 kI = e->h_blk_off[I + 1] - e->h_blk_off[I];
-            for (u64 tt = t; tt < stop; ++tt) {
-                u32 JJ = J + (u32)(tt - t);
-                u64 kJ = e->h_blk_off[JJ + 1] - e->h_blk_off[JJ];
-                bytes += (JJ == I) ? kI * (e->weighted ? 8 : 4) : (kI + kJ) * per;
-            }
+            u64 cnt = stop - t, J0 = J;
+            if (J0 == I) { bytes += kI * (e->weighted ? 8 : 4); ++J0; --cnt; }
+            if (cnt) bytes += (cnt * kI + (u64)(e->h_blk_off[J0 + cnt] - e->h_blk_off[J0])) * per;
             t = stop;
         }
         e->st.last_stream_bytes = bytes;

@@ -297,7 +297,7 @@ constexpr u32 HB_THREADS = 512;
 constexpr u32 HB_MEAN = 800;
 // The hand-written partition spreads the keys evenly over any number of buckets: the same mean the power-of-two
 // partition ends up with on real hash ranges (2^64 / scaled covers just over half of its power of two)
-constexpr u32 HB_HAND_MEAN = 2000;
+constexpr u32 HB_HAND_MEAN = 2000, HB_HAND_MEAN_MAX = 2400;
 constexpr u32 HB_KEPT = 1u << 31, HB_FIRST = 1u << 30;   // per-entry record: kept | first of its key | rank << 12 | place
 constexpr u32 HB_EMIT = 8;       // buckets per workgroup of the emit kernel
 constexpr u32 HB_BIG_CAP = 1024, HB_BIG_DISTINCT = 3072;   // k_bucket_big: buckets per build / distinct keys per bucket
