@@ -196,6 +196,20 @@ int kspider_pairwise(const char* index_prefix, int user_threads);
 int kspider_pairwise_sigs(const char* sigs_dir, int kSize, const char* out_prefix, int user_threads);
 int kspider_pairwise_bins(const char* bins_dir, const char* out_prefix, int user_threads);
 
+/* ---- clustering -------------------------------------------------------
+ * kspider_cluster: what `kSpider cluster -i PREFIX -d DIST -c CUTOFF` does (pykSpider/kSpider2/
+ *   ks_clustering.py:63-137, 150-163): reads PREFIX.namesMap, PREFIX_kSpider_seqToKmersNo.tsv and
+ *   PREFIX_kSpider_pairwise.tsv (dist_type "ani": also PREFIX_kSpider_pairwise.ani_col.tsv), keeps the rows
+ *   whose column dist_type ("min_cont" 3, "avg_cont" 4, "max_cont" 5; NULL = "max_cont") times 100 is not
+ *   below cutoff * 100 (cutoff in [0, 1]), finds the connected components ON THE GPU and writes one line of
+ *   comma-separated names per component to PREFIX_kSpider_clusters_<cutoff*100>%.tsv.  Components are
+ *   written in order of their smallest node, names in node order (the reference: rustworkx set order).
+ * ksp_components: the device part alone — connected components of an undirected edge list (host arrays
+ *   of node indices < n_nodes); h_label[v] = smallest node index of v's component.                      */
+int kspider_cluster(const char* index_prefix, const char* dist_type, double cutoff);
+int ksp_components(int device, uint32_t n_nodes, const uint32_t* h_a, const uint32_t* h_b, uint64_t n_edges,
+                   uint32_t* h_label);
+
 /* ---- host-only diagnostics (no GPU needed) -------------------------------------------
  * ksp_index_info: parse the three index files and report what the reader detected:
  * out[0] colours, out[1] groups, out[2] colour-count entries, out[3] sum of sources over

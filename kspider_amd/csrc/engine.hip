@@ -414,6 +414,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         KSP_HIP(hipMemcpyAsync(e->h_scal + 8, scal + 8, 8, hipMemcpyDeviceToHost, st));
         KSP_HIP(hipStreamSynchronize(st));
         nw = e->h_scal[8];
+        if (nw >= (1ull << 30)) { set_error("build_slice: more than 2^30 key entries in this slice (use more parts)"); return KSP_E_LIMIT; }
         if ((rc = e->FK.ensure((nw + 4) * 8))) return rc;
         if ((rc = e->FT.ensure((nw + 4) * sizeof(V)))) return rc;
         hipLaunchKernelGGL((k_range_copy<V, W>), dim3(N), dim3(128), 0, st, d_keys, d_w, d_off, first, cnt, fpos,
@@ -998,7 +999,10 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
         if (h_offsets[s + 1] < h_offsets[s]) { set_error("build: offsets not monotone"); return KSP_E_ARG; }
     const u64 n = n_sources ? h_offsets[n_sources] - h_offsets[0] : 0;
     if (n_sources && h_offsets[0] != 0) { set_error("build: offsets[0] must be 0"); return KSP_E_ARG; }
-    if (n >= (1ull << 30)) { set_error("build: more than 2^30 key entries per call"); return KSP_E_LIMIT; }
+    // 32-bit entry positions: a whole build takes fewer than 2^30 entries; a key-range slice of a larger set is
+    // fine as long as the slice itself stays below (checked once its size is known) — ksp_pairwise_host cuts such
+    // sets into enough slices by itself
+    if (n >= (1ull << 30) && !(slice && nparts > 1)) { set_error("build: more than 2^30 key entries per call"); return KSP_E_LIMIT; }
     if (n && !d_keys) { set_error("build: d_keys is NULL"); return KSP_E_ARG; }
     e->n_sources = n_sources;
     e->n_entries = n;
@@ -1751,6 +1755,20 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
     if (nd < 1 || nd > 64) { set_error("pairwise: between 1 and 64 devices"); return KSP_E_ARG; }
     const u32 N = job.n_sources;
     const u64 n = job.postings ? (job.n_keys ? job.key_off[job.n_keys] : 0) : (N ? job.offsets[N] : 0);
+    // A sketch set of 2^30 entries or more does not fit one build (32-bit entry positions): it is cut into hash-range
+    // slices of at most ~0.9 * 2^30 entries, built one engine each and assembled — the multi-GPU machinery with several
+    // workers per device ($KSP_SLICES forces a slice count: tests).
+    std::vector<int> expanded;
+    if (!job.postings) {
+        u64 want = n < (1ull << 30) ? 1 : n / 900000000ull + 1;   // (equal shares of the hash range: ~equal sizes for hashes)
+        if (const char* sl = std::getenv("KSP_SLICES")) want = std::max<u64>(want, (u64)std::max(1, std::atoi(sl)));
+        if (want > (u64)nd) {
+            if (want > 64) { set_error("pairwise_host: more than 2^35 key entries"); return KSP_E_LIMIT; }
+            for (u64 i = 0; i < want; ++i) expanded.push_back(devices[i % (u64)nd]);
+            devices = expanded.data();
+            nd = (int)want;
+        }
+    }
     struct Dev {
         ksp_engine* e = nullptr;
         void *d_a = nullptr, *d_b = nullptr;      // keys + weights, or sources + key weights
@@ -1759,6 +1777,7 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
         std::vector<u64> cuts;
         float ms_join = 0;
         int rc = KSP_OK;
+        bool borrowed = false;                    // d_a / d_b belong to another worker on the same device
         std::string err;
     };
     std::vector<Dev> dev((size_t)nd);
@@ -1781,7 +1800,10 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
         for (int j = 0; j < nd && !rc; ++j)   // direct xGMI copies between the devices of this job (already enabled: fine)
             if (devices[j] != device) { (void)hipDeviceEnablePeerAccess(devices[j], 0); (void)hipGetLastError(); }
         // ---- stage 1 --------------------------------------------------------------------------------------------
-        if (!failed.load() && n) {
+        int owner = i;   // the first worker on my device uploads the input; the others use its copy
+        for (int j = 0; j < i; ++j)
+            if (devices[j] == device) { owner = j; break; }
+        if (!failed.load() && n && owner == i) {
             if (job.postings) {
                 if ((rc = ksp_device_malloc(device, n * 4, &D.d_a)) || (rc = ksp_memcpy_h2d(D.d_a, job.sources, n * 4))) fail(rc);
                 if (!rc && job.key_weights &&
@@ -1793,6 +1815,8 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
                     fail(rc);
             }
         }
+        if (nd > 1 && sync_point()) return;   // (the uploads are complete: ksp_memcpy_h2d is synchronous)
+        if (owner != i) { D.d_a = dev[(size_t)owner].d_a; D.d_b = dev[(size_t)owner].d_b; D.borrowed = true; }
         if (!failed.load()) {
             if (job.postings)
                 rc = ksp_engine_build_postings(D.e, job.key_off, (const u32*)D.d_a, (const u32*)D.d_b, job.n_keys, N, nullptr);
@@ -1912,8 +1936,8 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
         Dev& D = dev[(size_t)i];
         if (D.rc && !rc) { rc = D.rc; set_error(D.err); }
         if (D.e) (void)hipSetDevice(D.e->device);
-        if (D.d_a) (void)hipFree(D.d_a);
-        if (D.d_b) (void)hipFree(D.d_b);
+        if (D.d_a && !D.borrowed) (void)hipFree(D.d_a);
+        if (D.d_b && !D.borrowed) (void)hipFree(D.d_b);
         D.edges.release(); D.labels.release();
         for (int q = 0; q < 6; ++q) { D.gather[q].release(); D.exp[q].release(); }
         ksp_engine_destroy(D.e);

@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "ksp_engine_build_postings", "ksp_pairwise_postings_host",
     "ksp_engine_set_profiling", "ksp_engine_phase_times",
     "ksp_pairwise_host_multi", "ksp_pairwise_postings_host_multi",
+    "kspider_cluster", "ksp_components",
 ]
 
 
@@ -115,6 +116,9 @@ def lib():
         L.ksp_engine_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.ksp_engine_phase_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p),
                                              ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+        L.kspider_cluster.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_double]
+        L.ksp_components.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                     ctypes.c_void_p]
         L.kspider_pairwise.argtypes = [ctypes.c_char_p, ctypes.c_int]
         L.ksp_index_info.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint64)]
         L.ksp_format_float.argtypes = [ctypes.c_float, ctypes.c_char_p]
@@ -194,6 +198,20 @@ def pairwise_postings_host(key_off: np.ndarray, sources: np.ndarray, key_weights
     finally:
         lib().ksp_free(out)
     return edges, st.as_dict()
+
+
+def cluster(index_prefix: str, dist_type: str = "max_cont", cutoff: float = 0.0) -> None:
+    """`kSpider cluster -i PREFIX -d DIST -c CUTOFF` (ks_clustering.py:150-163); components on the GPU."""
+    _check(lib().kspider_cluster(os.fsencode(index_prefix), dist_type.encode(), float(cutoff)))
+
+
+def components(n_nodes: int, a: np.ndarray, b: np.ndarray, device: int = 0) -> np.ndarray:
+    """Connected components of an undirected edge list on the GPU: label[v] = smallest node of v's component."""
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    b = np.ascontiguousarray(b, dtype=np.uint32)
+    out = np.empty(n_nodes, dtype=np.uint32)
+    _check(lib().ksp_components(device, n_nodes, a.ctypes.data, b.ctypes.data, a.size, out.ctypes.data))
+    return out
 
 
 def index_info(index_prefix: str) -> dict:

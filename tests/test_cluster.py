@@ -1,0 +1,147 @@
+"""Clustering: `kSpider cluster` = threshold the pairwise TSV + connected components
+(/root/reference/pykSpider/kSpider2/ks_clustering.py:63-137).
+
+CPU: the oracle's restatement against the golden cluster files that the REFERENCE's own Clusters class wrote
+(tests/golden/make_cluster_golden.py), compared as sets of components — the golden files carry the stand-in's
+order, not rustworkx's.  GPU: kspider_cluster() (components on the device) against the oracle byte for byte
+(both use the canonical order) and against the golden sets; ksp_components() against a union-find on graphs
+with long chains, stars, isolated nodes and a million nodes."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from oracle import ref_cluster
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "clusters")
+CASES = [("max_cont", 0.0), ("max_cont", 0.3), ("avg_cont", 0.25), ("min_cont", 0.07), ("min_cont", 0.5), ("max_cont", 1.0)]
+
+
+def _as_sets(path):
+    return sorted(tuple(sorted(l.rstrip("\n").split(","))) for l in open(path) if l.strip())
+
+
+def _stage(tag, tmp_path):
+    d = tmp_path / tag
+    shutil.copytree(os.path.join(GOLD, tag), d)
+    return str(d / "sigs")
+
+
+@pytest.mark.parametrize("tag", ["setA", "setB"])
+def test_oracle_matches_reference_clusters(tag, tmp_path):
+    prefix = _stage(tag, tmp_path)
+    for dist, cutoff in CASES:
+        out = ref_cluster.write_clusters(prefix, dist, cutoff)
+        # the reference names the file with the Python repr of cutoff * 100 (0.07 -> 7.000000000000001)
+        assert os.path.basename(out) == f"sigs_kSpider_clusters_{float(cutoff) * 100}%.tsv"
+        want = _as_sets(os.path.join(GOLD, tag, f"ref_{dist}_{cutoff}.clusters"))
+        assert _as_sets(out) == want, (tag, dist, cutoff)
+        names = [n for comp in want for n in comp]
+        n_nodes = int(open(prefix + ".namesMap").readline())
+        assert len(names) == len(set(names)) == n_nodes   # every node in exactly one component, singletons included
+        os.remove(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["setA", "setB"])
+def test_gpu_clusters_equal_oracle_and_reference(tag, tmp_path):
+    from kspider_amd import engine
+    prefix = _stage(tag, tmp_path)
+    for dist, cutoff in CASES:
+        want_path = ref_cluster.write_clusters(prefix, dist, cutoff)
+        want = open(want_path, "rb").read()
+        os.remove(want_path)
+        engine.cluster(prefix, dist, cutoff)
+        assert os.path.exists(want_path), "file name differs from the reference's"
+        assert open(want_path, "rb").read() == want
+        assert _as_sets(want_path) == _as_sets(os.path.join(GOLD, tag, f"ref_{dist}_{cutoff}.clusters"))
+        assert not os.path.exists(want_path + ".partial")
+        os.remove(want_path)
+
+
+@pytest.mark.gpu
+def test_gpu_cluster_after_gpu_pairwise_and_loud_failures(oracle_lib, tmp_path):
+    """index -> kspider_pairwise (HIP) -> kspider_cluster (HIP), against the oracle's pairwise + clustering."""
+    from kspider_amd import engine, synth
+    sk = synth.generate("C2", n_sources=400, mean_size=300, cluster_cap=25, seed=1234)
+    prefix = str(tmp_path / "ix")
+    oracle_lib.index_from_sketches(prefix, sk.keys, sk.offsets)
+    with open(prefix + ".namesMap", "w") as f:
+        f.write(f"{sk.n_sources}\n")
+        for i in range(sk.n_sources):
+            f.write(f"{i + 1} genome_{i + 1}\n")
+    engine.pairwise(prefix, 2)
+    for dist, cutoff in (("max_cont", 0.2), ("min_cont", 0.05), ("avg_cont", 0.6)):
+        engine.cluster(prefix, dist, cutoff)
+        got = open(ref_cluster.output_path(prefix, cutoff), "rb").read()
+        os.remove(ref_cluster.output_path(prefix, cutoff))
+        assert got == open(ref_cluster.write_clusters(prefix, dist, cutoff), "rb").read()
+        assert 1 < got.count(b"\n") < sk.n_sources
+    # failures are loud: unknown distance, ANI without its file, a namesMap that does not cover the nodes
+    with pytest.raises(engine.KspError):
+        engine.cluster(prefix, "jaccard", 0.1)
+    with pytest.raises(engine.KspError) as ei:
+        engine.cluster(prefix, "ani", 0.1)
+    assert "ani_col" in str(ei.value)
+    with open(prefix + ".namesMap", "w") as f:
+        f.write("2\n1 a\n2 b\n")
+    with pytest.raises(engine.KspError) as ei:
+        engine.cluster(prefix, "max_cont", 0.0)
+    assert ei.value.code == engine.KSP_E_IO
+
+
+def _union_find(n, a, b):
+    parent = np.arange(n)
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for u, v in zip(a.tolist(), b.tolist()):
+        ru, rv = find(u), find(v)
+        if ru != rv:
+            parent[max(ru, rv)] = min(ru, rv)
+    return np.array([find(v) for v in range(n)], dtype=np.uint32)
+
+
+@pytest.mark.gpu
+def test_components_kernel():
+    from kspider_amd import engine
+    rng = np.random.default_rng(5)
+    # no edges, no nodes
+    assert engine.components(0, np.zeros(0, np.uint32), np.zeros(0, np.uint32)).size == 0
+    assert (engine.components(7, np.zeros(0, np.uint32), np.zeros(0, np.uint32)) == np.arange(7)).all()
+    # a 50 000-node chain given in shuffled order (deep trees), a star, self loops, duplicate edges, isolated nodes
+    n = 60_000
+    chain = np.arange(50_000, dtype=np.uint32)
+    a = np.concatenate([chain[:-1], np.full(3000, 50_010, np.uint32), [7, 7, 9]]).astype(np.uint32)
+    b = np.concatenate([chain[1:], np.arange(52_000, 55_000, dtype=np.uint32), [7, 8, 9]]).astype(np.uint32)
+    p = rng.permutation(a.size)
+    lab = engine.components(n, a[p], b[p])
+    assert (lab == _union_find(n, a, b)).all()
+    assert (lab[:50_000] == 0).all() and lab[59_999] == 59_999
+    # random sparse graph, 200 000 nodes
+    n = 200_000
+    a = rng.integers(0, n, size=150_000, dtype=np.uint32)
+    b = rng.integers(0, n, size=150_000, dtype=np.uint32)
+    assert (engine.components(n, a, b) == _union_find(n, a, b)).all()
+    # an index beyond the node count is refused
+    with pytest.raises(engine.KspError):
+        engine.components(5, np.array([1], np.uint32), np.array([5], np.uint32))
+    # 2 M nodes, 6 M edges in clusters: labels are the smallest member, consistent along every edge
+    n = 2_000_000
+    grp = rng.integers(0, 50_000, size=n)
+    order = np.argsort(grp, kind="stable")
+    a = order[:-1].astype(np.uint32)
+    b = order[1:].astype(np.uint32)
+    same = grp[a] == grp[b]
+    a, b = a[same], b[same]
+    extra = rng.integers(0, a.size, size=4_000_000)
+    a2, b2 = np.concatenate([a, a[extra]]), np.concatenate([b, b[np.roll(extra, 1)]])
+    keep = grp[a2] == grp[b2]
+    lab = engine.components(n, a2[keep], b2[keep])
+    first = np.full(50_000, n, dtype=np.int64)
+    np.minimum.at(first, grp, np.arange(n))
+    assert (lab == first[grp]).all()

@@ -80,3 +80,12 @@ def test_dropin_tsv_bytes_equal_under_kspider_devices(oracle_lib, tmp_path):
     env = dict(os.environ, KSPIDER_DEVICES="0,99")
     p = subprocess.run([exe, prefix, "2"], capture_output=True, env=env)
     assert p.returncode != 0 and not os.path.exists(prefix + "_kSpider_pairwise.tsv")
+
+
+def test_forced_slices_on_one_device(oracle_lib, monkeypatch):
+    """$KSP_SLICES: the sequential-slice path that lifts the 2^30-entry limit of one build, on a small set."""
+    sk = synth.generate("C2", n_sources=700, mean_size=600, cluster_cap=40, seed=812)
+    one, _ = engine.pairwise_host(sk.keys, sk.offsets)
+    monkeypatch.setenv("KSP_SLICES", "3")
+    sliced, _ = engine.pairwise_host(sk.keys, sk.offsets)
+    assert len(one) == len(sliced) > 1000 and (one == sliced).all()
