@@ -63,6 +63,9 @@ typedef struct ksp_stats {
     int partition_fallback;     /* 0, or why the hand-written partition handed the build to rocPRIM: 1 page
                                    table / pool full (keys far from uniform), 2 internal count mismatch,
                                    3 page wait timed out — 2 and 3 are defects, never expected            */
+    uint64_t n_match_records;   /* match-list join: (key, block pair) records stage 1 handed to the join (0: the
+                                   join searches the block lists)                                         */
+    uint64_t n_join_workgroups; /* shares of the work list (workgroups of a join over all tiles)           */
 } ksp_stats;
 
 const char* ksp_last_error(void);

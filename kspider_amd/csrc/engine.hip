@@ -149,6 +149,10 @@ struct ksp_engine {
     std::vector<u64> act_tid;     // active tiles (row-major tile ids, ascending)
     std::vector<u32> act_rec;     // per active tile: I, J, first workgroup, split index (+ one sentinel record)
     ksp::Buf tbits, dwork, d_act, d_wg;
+    // match-list join (inputs whose list words have few holders): records sorted by tile, first record per active tile
+    ksp::Buf mcnt, moff, mt0, mt1, mr0, mr1, mstart;
+    bool matches_on = false;      // mt1 / mr1 hold this build's records
+    u64 n_matches = 0;
     unsigned char* h_stage = nullptr;   // pinned: diagonal work + overflow flag, then the tile bitmap
     size_t h_stage_bytes = 0;
     unsigned char* h_blk_stage = nullptr;   // pinned: per-block maxima, then the list offsets (stage_block_tables)
@@ -156,6 +160,7 @@ struct ksp_engine {
     bool blk_staged = false;
     bool d_off_sketch = false;          // d_off holds the sketch offsets of h_off (an unchanged set is not uploaded again)
     std::vector<u32> wg_host;           // share -> active tile (kept alive for the asynchronous upload)
+    std::vector<u32> h_mstart;          // match-list mode: first record of every active tile (+ sentinel)
     unsigned long long* h_count = nullptr;   // pinned
     u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
     u64 sort_entries = 0;                    // entries / key bits of the last global radix sort (stats)
@@ -770,6 +775,42 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     }
     hipLaunchKernelGGL(k_tile_flags, dim3(grid_for(K, 256)), dim3(256), 0, st, pr2, pb2, K, nb, flags);
     hipLaunchKernelGGL(k_pack_flags, dim3(grid_for(T, 256)), dim3(256), 0, st, flags, T, e->tbits.as<u32>());
+    // match records for the join (sparse sharing: few holders per list word — the lists are long and a block pair
+    // matches next to nothing of them; KSP_JOIN=matches / search forces the choice)
+    e->matches_on = false;
+    e->n_matches = 0;
+    {
+        const char* jm = std::getenv("KSP_JOIN");
+        const bool force = jm && std::string(jm) == "matches", never = jm && std::string(jm) != "matches";
+        if (ranked && !e->weighted && !never && K < (1ull << 31) && (force || e->n_kept < 4 * K)) {
+            phase_mark(e, st, "match records");
+            if ((rc = e->mcnt.ensure((K + 4) * 4))) return rc;
+            if ((rc = e->moff.ensure((K + 4) * 8))) return rc;
+            hipLaunchKernelGGL(k_match_count, dim3(grid_for(K, 256)), dim3(256), 0, st, pr2, (u32)K, e->mcnt.as<u32>());
+            size_t tb = 0;
+            KSP_HIP(rocprim::exclusive_scan(nullptr, tb, e->mcnt.as<u32>(), e->moff.as<u64>(), (u64)0, (size_t)K, rocprim::plus<u64>(), st));
+            if ((rc = e->tmp.ensure(tb))) return rc;
+            KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, e->mcnt.as<u32>(), e->moff.as<u64>(), (u64)0, (size_t)K, rocprim::plus<u64>(), st));
+            KSP_HIP(hipMemcpyAsync(e->h_scal + 12, e->moff.as<u64>() + (K - 1), 8, hipMemcpyDeviceToHost, st));
+            KSP_HIP(hipMemcpyAsync(e->h_scal + 13, e->mcnt.as<u32>() + (K - 1), 4, hipMemcpyDeviceToHost, st));
+            KSP_HIP(hipStreamSynchronize(st));   // (the record count sizes the buffers and the sort)
+            const u64 M = e->h_scal[12] + (u32)e->h_scal[13];
+            if (M > 0 && M < (1ull << 31) && M <= 32 * K) {
+                if ((rc = e->mt0.ensure(M * 4)) || (rc = e->mt1.ensure(M * 4)) || (rc = e->mr0.ensure(M * 8)) || (rc = e->mr1.ensure(M * 8))) return rc;
+                const u64* rec_val = e->gp.as<u64>();
+                hipLaunchKernelGGL(k_match_emit, dim3(grid_for(K, 256)), dim3(256), 0, st, pr2, pb2, rec_val, (u32)K, e->moff.as<u64>(), nb,
+                                   e->mt0.as<u32>(), e->mr0.as<u64>());
+                int tbits_n = 1;
+                while (tbits_n < 32 && (T >> tbits_n)) ++tbits_n;
+                tb = 0;
+                KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, e->mt0.as<u32>(), e->mt1.as<u32>(), e->mr0.as<u64>(), e->mr1.as<u64>(), (size_t)M, 0, tbits_n, st));
+                if ((rc = e->tmp.ensure(tb))) return rc;
+                KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, e->mt0.as<u32>(), e->mt1.as<u32>(), e->mr0.as<u64>(), e->mr1.as<u64>(), (size_t)M, 0, tbits_n, st));
+                e->matches_on = true;
+                e->n_matches = M;
+            }
+        }
+    }
     // results to pinned host memory in stream order: the caller's end-of-build synchronisation covers them
     const size_t stage_bytes = bit_words * 4 + ((size_t)nb + 2) * 8;
     if (e->h_stage_bytes < stage_bytes) {
@@ -831,7 +872,8 @@ void ksp_engine_destroy(ksp_engine* e) {
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
-                        &e->d_wg, &e->gp, &e->gm, &e->PK, &e->PT, &e->PD, &e->parena};
+                        &e->d_wg, &e->gp, &e->gm, &e->PK, &e->PT, &e->PD, &e->parena, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
+                        &e->mr0, &e->mr1, &e->mstart};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
@@ -884,25 +926,45 @@ static int build_schedule(ksp_engine* e) {
         if (I == J && !e->weighted) return 40 * words_of(I) + 20000;   // bit-sliced: 16 popcounts x 528 patches per 64 keys
         return I == J ? dw[I] / 2 + 10 * words_of(I) + 20000 : 8 * (words_of(I) + words_of(J)) + 20000;
     };
-    // pass 1: active tiles and total cost
+    // pass 1: active tiles
     u64 total = 0;
     e->act_tid.reserve((size_t)active);
     const char* only = std::getenv("KSP_DEBUG_ONLY");   // timing experiments: "diag" / "off" (results are incomplete)
     const bool skip_diag = only && std::string(only) == "off", skip_off = only && std::string(only) == "diag";
     for (u32 I = 0; I < nb; ++I) {
         const u64 row = tile_row_start(I, nb);
-        if (dw[I] && !skip_diag) { e->act_tid.push_back(row); total += cost_of(I, I); }
+        if (dw[I] && !skip_diag) e->act_tid.push_back(row);
         for (u64 t = row + 1; !skip_off && t < row + (nb - I);) {
             const u32 wrd = bits[t >> 5] >> (t & 31);
             if (!wrd) { t = (t | 31) + 1; continue; }
             const u64 tt = t + (u64)__builtin_ctz(wrd);
             if (tt >= row + (nb - I)) break;
             e->act_tid.push_back(tt);
-            total += cost_of(I, I + (u32)(tt - row));
             t = tt + 1;
         }
     }
     const size_t A = e->act_tid.size();
+    // match-list mode: the records of every tile (their number is the tile's work: a few heavy tiles hold most of them)
+    std::vector<u32>& ms = e->h_mstart;
+    ms.clear();
+    if (e->matches_on) {
+        std::vector<u32> tids(A + 1, 0);
+        for (size_t i = 0; i < A; ++i) tids[i] = (u32)e->act_tid[i];
+        if ((rc = e->mstart.ensure((A + 2) * 4)) || (rc = e->d_act.ensure((4 * (A + 1)) * 4))) return rc;
+        ms.resize(A + 1);
+        KSP_HIP(hipMemcpyAsync(e->d_act.p, tids.data(), (A + 1) * 4, hipMemcpyHostToDevice, e->sched_stream));   // (d_act: scratch until the records go up)
+        hipLaunchKernelGGL(k_match_bounds, dim3(grid_for(A + 1, 256)), dim3(256), 0, e->sched_stream, e->d_act.as<u32>(), (u32)A,
+                           e->mt1.as<u32>(), (u32)e->n_matches, e->mstart.as<u32>());
+        KSP_HIP(hipMemcpyAsync(ms.data(), e->mstart.p, (A + 1) * 4, hipMemcpyDeviceToHost, e->sched_stream));
+        KSP_HIP(hipStreamSynchronize(e->sched_stream));
+    }
+    std::vector<u64> cost(A);
+    for (size_t i = 0; i < A; ++i) {
+        u32 I, J;
+        tile_decode(e->act_tid[i], nb, I, J);
+        cost[i] = (e->matches_on && I != J) ? 6 * (u64)(ms[i + 1] - ms[i]) + 20000 : cost_of(I, J);
+        total += cost[i];
+    }
     // (a sharded job joins 1/nparts of the list per GPU: size the shares for that)
     u64 quarter_shares = 2;   // shares per workgroup slot of the chip, in quarters: half a wave of workgroups measured best
                               // on C2 (0.46 ms vs 0.55 at one per slot, 0.84 at three); KSP_DEBUG_SHARES: experiments
@@ -917,8 +979,15 @@ static int build_schedule(ksp_engine* e) {
     for (size_t i = 0; i < A; ++i) {
         u32 I, J;
         tile_decode(e->act_tid[i], nb, I, J);
-        u64 sp = (cost_of(I, J) + target - 1) / target;
+        u64 sp = (cost[i] + target - 1) / target;
         sp = std::min<u64>(std::max<u64>(sp, 1), 32);
+        if (e->matches_on && I != J) {
+            // a share of records, not of estimated cycles: a round of 512 records is a chain of memory round trips,
+            // and a few tiles hold most of the records (the blocks of the largest sketches) — as one workgroup each
+            // they were the whole join (C4: 16 of 19 ms)
+            const u64 per_share = std::min<u64>(std::max<u64>(e->n_matches / ((u64)e->slots * 4) + 1, 8192), 1u << 20);
+            sp = std::min<u64>(std::max<u64>(((u64)(ms[i + 1] - ms[i]) + per_share - 1) / per_share, 1), 1024);
+        }
         u32* r = &e->act_rec[4 * i];
         r[0] = I; r[1] = J; r[2] = (u32)wg.size(); r[3] = nsplit;
         if (sp > 1) ++nsplit;
@@ -933,6 +1002,8 @@ static int build_schedule(ksp_engine* e) {
     if (!wg.empty()) KSP_HIP(hipMemcpyAsync(e->d_wg.p, wg.data(), wg.size() * 4, hipMemcpyHostToDevice, e->sched_stream));
     e->sched_on = true;
     e->st.n_active_tiles = A;
+    e->st.n_match_records = e->matches_on ? e->n_matches : 0;
+    e->st.n_join_workgroups = wg.size();
     return KSP_OK;
 }
 
@@ -993,7 +1064,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     KSP_HIP(hipSetDevice(e->device));
     e->built = false;
     e->slice_ready = false;
-    e->sched_on = false; e->collect = false; e->have_bits = false;   // (nothing of the previous build's work list survives)
+    e->sched_on = false; e->collect = false; e->have_bits = false; e->matches_on = false;   // (nothing of the previous build's work list survives)
     e->act_tid.clear(); e->act_rec.clear();
     for (u32 s = 0; s < n_sources; ++s)
         if (h_offsets[s + 1] < h_offsets[s]) { set_error("build: offsets not monotone"); return KSP_E_ARG; }
@@ -1095,7 +1166,7 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
     KSP_HIP(hipSetDevice(e->device));
     e->built = false;
     e->slice_ready = false;
-    e->sched_on = false; e->collect = false; e->have_bits = false;
+    e->sched_on = false; e->collect = false; e->have_bits = false; e->matches_on = false;
     e->act_tid.clear(); e->act_rec.clear();
     e->ph_n = 0;
     e->slice_phase = 0;
@@ -1458,6 +1529,7 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     a.inv = e->smap.as<u32>() + 3 * (((size_t)e->n_sources + 64) & ~(size_t)63);
     a.sched = nullptr; a.act = nullptr; a.wg0 = 0; a.split0 = 0; a.tail_done = nullptr;
     a.collect = e->collect ? 1u : 0u;
+    a.mrec = nullptr; a.mstart = nullptr;
     auto launch = [&](bool c16, dim3 grid, const JoinArgs& args) {
         if (e->use_cells) {
             if (e->weighted) { if (c16) hipLaunchKernelGGL((k_join<true, true, true>), grid, block, 0, st, args); else hipLaunchKernelGGL((k_join<true, false, true>), grid, block, 0, st, args); }
@@ -1480,6 +1552,7 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
         const u32 spA = e->act_rec[4 * act0 + 3], spB = e->act_rec[4 * act1 + 3];
         a.sched = e->d_wg.as<u32>();
         a.act = e->d_act.as<u32>();
+        if (e->matches_on) { a.mrec = e->mr1.as<u64>(); a.mstart = e->mstart.as<u32>(); }
         a.split0 = spA;
         a.n_normal = 0; a.tail_sp = 1;
         a.tailbuf = nullptr;

@@ -35,6 +35,11 @@ struct JoinArgs {
     u32* tailbuf;       // n_tail x TB*TB 32-bit counters the tail workgroups add into
     u32* tail_done;     // work-list mode: per split tile, the shares that have added their counters
     u32 dbg;            // timing-only ablation switches (-DKSP_ABLATE builds + KSP_DEBUG_ABLATE; results are wrong when set)
+    // match-list mode (work-list mode only; NULL: the lists are searched): stage 1 has already paired the list words
+    // of every key that sits in two blocks — one record (posting word of the I side | posting word of the J side
+    // << 32) per (key, block pair), sorted by tile; tile `i` of the work list owns mrec[mstart[i] .. mstart[i + 1])
+    const u64* mrec;
+    const u32* mstart;
 };
 
 __host__ __device__ inline u64 tile_row_start(u64 r, u64 nb) { return r * nb - r * (r - 1) / 2; }
@@ -494,7 +499,7 @@ __device__ inline void join_cells(const JoinArgs& a, u32* S, WaveLds& wl, const 
 // write (pass 1 over its registers / counters), the wave totals meet in LDS, one lane reserves the whole tile's
 // range and every wave gets its start; pass 2 writes.  (One atomic per wave and emitted row — all on the same
 // word, which the memory side serves one at a time — was most of the join on inputs with many small tiles:
-// C5, 1 M sources: 21.4 -> x ms.)  `scratch`: JW + 2 words of LDS nobody else touches between the two barriers.
+// C5, 1 M sources: 21.4 -> 1.05 ms; C3: 10.4 -> 3.8 ms.)  `scratch`: JW + 2 words of LDS nobody else touches between the two barriers.
 __device__ inline u64 emit_reserve(const JoinArgs& a, u32* scratch, const u32 wave_count, const int tid, const int lane,
                                    const int wv) {
     if (lane == 0) scratch[wv] = wave_count;
@@ -859,6 +864,118 @@ __device__ inline void join_cells_collect(const JoinArgs& a, unsigned char* smem
         }
 }
 
+// ---- off-diagonal tile from its match records (no search) ---------------------------------------
+// Inputs whose keys are shared by few sources each (metagenome bins: ~2 holders per list word) have long
+// block lists of which a given block pair matches next to nothing: searching them costs two full lists per
+// tile.  Stage 1 knows every key's blocks, so it can hand the join the matches themselves (k_match_emit):
+// this share's slice of the tile's records is applied to the counter tile, one record per lane and step.
+template <bool C16>
+__device__ inline void join_matches_counters(const JoinArgs& a, u32* S, WaveLds& wl, const u32 r0, const u32 r1,
+                                             const int tid, const int lane) {
+    constexpr u32 UN = 4;   // records per lane and round: four loads in flight instead of one round trip per record
+    for (u32 base = r0; base < r1; base += UN * JW * 64) {   // (uniform trip count: pending_apply is wave-wide)
+        u64 rec[UN];
+#pragma unroll
+        for (u32 k = 0; k < UN; ++k) {
+            const u32 i = base + k * JW * 64 + (u32)tid;
+            rec[k] = i < r1 ? a.mrec[i] : ~0ull;
+        }
+#pragma unroll
+        for (u32 k = 0; k < UN; ++k) {
+            if (base + k * JW * 64 >= r1) break;   // (uniform)
+            Pending q;
+            q.valid = rec[k] != ~0ull;             // (no record is all ones: a posting word never is)
+            q.ia = (u32)rec[k];
+            q.ib = (u32)(rec[k] >> 32);
+            q.w = 1;
+            pending_apply<C16>(S, wl.lst, a.bigmask, q, lane);
+        }
+    }
+}
+// ... or accumulated bit-sliced, as join_cells_collect does with the matches it finds (multi-source postings)
+template <int S_BYTES, bool C16>
+__device__ inline void join_matches_collect(const JoinArgs& a, unsigned char* smem, const u32 I, const u32 J, const u32 r0,
+                                            const u32 r1, u32* __restrict__ dst, const int tid, const int lane, const int wv) {
+    CollectLds& cl = *reinterpret_cast<CollectLds*>(smem);
+    const u32 pi0 = (u32)tid >> 5, pi1 = pi0 + 16u, pj = (u32)tid & 31u;
+    constexpr int NA = C16 ? 8 : 16;
+    u32 acc0[NA], acc1[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) { acc0[i] = 0; acc1[i] = 0; }
+    for (u32 mb = r0; mb < r1; mb += MSUB) {
+        const u32 mi = mb + 64u * (u32)wv + (u32)lane;
+        uint4 ma = make_uint4(0, 0, 0, 0), mbm = ma;
+        if (mi < r1) {
+            const u64 rec = a.mrec[mi];
+            ma = posting_mask((u32)rec, a.bigmask);
+            mbm = posting_mask((u32)(rec >> 32), a.bigmask);
+        }
+        if (mb + 64u * (u32)wv < r1) {   // wave-uniform
+            cl.col[0][wv][lane] = transpose64((u64)ma.x | ((u64)ma.y << 32), lane);
+            __builtin_amdgcn_sched_barrier(0);
+            cl.col[0][wv][64 + lane] = transpose64((u64)ma.z | ((u64)ma.w << 32), lane);
+            __builtin_amdgcn_sched_barrier(0);
+            cl.col[1][wv][lane] = transpose64((u64)mbm.x | ((u64)mbm.y << 32), lane);
+            __builtin_amdgcn_sched_barrier(0);
+            cl.col[1][wv][64 + lane] = transpose64((u64)mbm.z | ((u64)mbm.w << 32), lane);
+        }
+        __syncthreads();
+        const u32 ng = min((u32)(MSUB / 64), (r1 - mb + 63u) / 64u);
+#pragma unroll 1
+        for (u32 g = 0; g < ng; ++g) {
+            const ulonglong2* cc = reinterpret_cast<const ulonglong2*>(&cl.col[1][g][4u * pj]);
+            const ulonglong2 c01 = cc[0], c23 = cc[1];
+            const u64 cw[4] = {c01.x, c01.y, c23.x, c23.y};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const ulonglong2* rr = reinterpret_cast<const ulonglong2*>(&cl.col[0][g][4u * (h ? pi1 : pi0)]);
+                const ulonglong2 x01 = rr[0], x23 = rr[1];
+                const u64 rw[4] = {x01.x, x01.y, x23.x, x23.y};
+                u32* acc = h ? acc1 : acc0;
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 4; y += 2) {
+                        const u32 v0 = (u32)__popcll(rw[x] & cw[y]), v1 = (u32)__popcll(rw[x] & cw[y + 1]);
+                        if (C16) acc[2 * x + y / 2] += v0 | (v1 << 16);
+                        else { acc[4 * x + y] += v0; acc[4 * x + y + 1] += v1; }
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    const u32 gi = I * TB, gj = J * TB;
+    u64 wpos = 0;
+    if (!dst) {
+        u32 cnt = 0;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) {
+                cnt += count_nz(C16 ? (acc0[2 * x + y / 2] >> (16 * (y & 1))) & 0xFFFFu : acc0[C16 ? 0 : 4 * x + y]);
+                cnt += count_nz(C16 ? (acc1[2 * x + y / 2] >> (16 * (y & 1))) & 0xFFFFu : acc1[C16 ? 0 : 4 * x + y]);
+            }
+        __syncthreads();
+        wpos = emit_reserve(a, reinterpret_cast<u32*>(smem), cnt, tid, lane, wv);
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            const u32 r0c = 4u * pi0 + (u32)x, r1c = 4u * pi1 + (u32)x, cc = 4u * pj + (u32)y;
+            const u32 v0 = C16 ? (acc0[2 * x + y / 2] >> (16 * (y & 1))) & 0xFFFFu : acc0[C16 ? 0 : 4 * x + y];
+            const u32 v1 = C16 ? (acc1[2 * x + y / 2] >> (16 * (y & 1))) & 0xFFFFu : acc1[C16 ? 0 : 4 * x + y];
+            if (dst) {
+                if (v0) atomicAdd(&dst[r0c * TB + cc], v0);
+                if (v1) atomicAdd(&dst[r1c * TB + cc], v1);
+            } else {
+                emit_at(a, gi + r0c, gj + cc, v0, lane, wpos);
+                emit_at(a, gi + r1c, gj + cc, v1, lane, wpos);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
 template <bool W, bool C16, bool CELLS>
 __global__ __launch_bounds__(JW * 64, 6) void k_join(JoinArgs a) {   // (6 waves per SIMD = three workgroups per CU: caps the unweighted variant at 80 VGPRs)
     // pair counters (32 KB packed 16-bit / 64 KB 32-bit) + 8 x (1.3 KB B window + 0.5 KB match
@@ -875,9 +992,12 @@ __global__ __launch_bounds__(JW * 64, 6) void k_join(JoinArgs a) {   // (6 waves
     // into tail_sp rank-range shares each, so that the round takes 1/tail_sp of a tile time.
     u32 sub = 0, sp = 1, tail_id = 0xFFFFFFFFu;
     u32 I, J;
+    u32 mr0 = 0, mr1 = 0;   // match-list mode: this share's records
     if (a.sched) {
         const u32 wg = a.wg0 + blockIdx.x;
-        const u32* t = a.act + 4 * (size_t)a.sched[wg];
+        const u32 ai = a.sched[wg];
+        const u32* t = a.act + 4 * (size_t)ai;
+        if (a.mrec) { mr0 = a.mstart[ai]; mr1 = a.mstart[ai + 1]; }
         I = t[0]; J = t[1];
         sub = wg - t[2];
         sp = t[6] - t[2];                       // (next tile's first workgroup)
@@ -898,11 +1018,18 @@ __global__ __launch_bounds__(JW * 64, 6) void k_join(JoinArgs a) {   // (6 waves
     // 16-bit counters are exact iff one of the two blocks has no source with >= 2^16 k-mers
     if ((min(a.blk_max[I], a.blk_max[J]) < 65536u) != C16) return;
 
+    const bool matches = !W && a.mrec != nullptr && I != J;
+    if (matches) {   // this share's slice of the tile's records
+        const u32 n = mr1 - mr0;
+        mr1 = mr0 + (u32)(((u64)n * (sub + 1)) / sp);
+        mr0 = mr0 + (u32)(((u64)n * sub) / sp);
+    }
     const bool popc = !W && a.collect && (I == J || CELLS);
     if (popc) {
         // unweighted tiles: bit-sliced accumulation in registers (no counter tile, no LDS atomics)
         u32* dst = tail_id != 0xFFFFFFFFu ? a.tailbuf + (size_t)tail_id * (TB * TB) : nullptr;
         if (I == J) self_tile_popc<SMEM_BYTES>(a, smem, I, sub, sp, dst, tid, lane, wv);
+        else if (matches) join_matches_collect<S_BYTES, C16>(a, smem, I, J, mr0, mr1, dst, tid, lane, wv);
         else join_cells_collect<S_BYTES, C16>(a, smem, wlds[wv], I, J, sub, sp, dst, tid, lane, wv);
         if (!dst) return;
     } else {
@@ -943,6 +1070,8 @@ __global__ __launch_bounds__(JW * 64, 6) void k_join(JoinArgs a) {   // (6 waves
                 add_masks<true, C16>(S, wlds[wv].lst, m, m, sw, lane);
             }
         }
+    } else if (matches) {
+        join_matches_counters<C16>(a, S, wlds[wv], mr0, mr1, tid, lane);
     } else if (CELLS) {
         join_cells<W, C16>(a, S, wlds[wv], I, J, wv, lane, sub, sp);
     } else {

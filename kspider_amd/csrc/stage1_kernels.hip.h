@@ -1171,6 +1171,46 @@ __global__ void k_pack_flags(const unsigned char* __restrict__ flags, u64 n, u32
     if ((threadIdx.x & 63) == 0 && t < n) { bits[t >> 5] = (u32)m; bits[(t >> 5) + 1] = (u32)(m >> 32); }
 }
 
+// ---- match records (see join_matches_counters in join_kernels.hip.h) -----------------------------
+// The group records of the key-by-key build are in rank order: the list words of one key are adjacent.  Every
+// pair of them is one match of the join — (tile of the two blocks, posting word of the lower block, posting
+// word of the higher block).  Counted per leading word, scanned, emitted, sorted by tile (host side).
+__global__ void k_match_count(const u32* __restrict__ rank, u32 n_groups, u32* __restrict__ cnt) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const u32 r = rank[g];
+    u32 c = 0;
+    for (u32 j = g + 1; j < n_groups && rank[j] == r; ++j) ++c;
+    cnt[g] = c;
+}
+__global__ void k_match_emit(const u32* __restrict__ rank, const u32* __restrict__ blk, const u64* __restrict__ val,
+                             u32 n_groups, const u64* __restrict__ off, u32 nb, u32* __restrict__ mt, u64* __restrict__ mr) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const u32 r = rank[g], bg = blk[g], ig = (u32)val[g];
+    u64 o = off[g];
+    for (u32 j = g + 1; j < n_groups && rank[j] == r; ++j, ++o) {   // (a key's first word is its first holder's block, the others ascend)
+        const u32 bj = blk[j], ij = (u32)val[j];
+        const u32 I = min(bg, bj), J = max(bg, bj);
+        mt[o] = (u32)(tile_row_start_dev(I, nb) + (J - I));
+        mr[o] = bg < bj ? ((u64)ig | ((u64)ij << 32)) : ((u64)ij | ((u64)ig << 32));
+    }
+}
+// first record of every tile of the work list (tid: the tile ids, ascending)
+__global__ void k_match_bounds(const u32* __restrict__ tid, u32 n_act, const u32* __restrict__ mt, u32 n_rec,
+                               u32* __restrict__ mstart) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_act) return;
+    if (i == n_act) { mstart[i] = n_rec; return; }
+    const u32 t = tid[i];
+    u32 lo = 0, hi = n_rec;
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        if (mt[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    mstart[i] = lo;
+}
+
 // ---- key-range slices (multi-GPU build) -----------------------------------------------
 // Rank p of G builds the block lists of the keys in its 1/G share of the hash range only
 // (filter -> same pipeline on n/G entries); the slices are exchanged (all-gather) and every

@@ -43,6 +43,7 @@ class Stats(ctypes.Structure):
         ("key_bits", ctypes.c_int), ("n_active_tiles", ctypes.c_uint64), ("last_active_tiles", ctypes.c_uint64),
         ("sort_entries", ctypes.c_uint64), ("ms_sort", ctypes.c_float), ("sort_bits", ctypes.c_int),
         ("partition_kind", ctypes.c_int), ("partition_fallback", ctypes.c_int),
+        ("n_match_records", ctypes.c_uint64), ("n_join_workgroups", ctypes.c_uint64),
     ]
 
     def as_dict(self):

@@ -13,15 +13,17 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["default", "no_reorder", "dense_walk", "collect", "lds_counters", "sort_grouping", "sort_lists",
-                                      "rocprim_partition"])
+                                      "rocprim_partition", "match_join"])
 def mode(request, monkeypatch):
     """Every case runs seven ways (the last two: keys grouped by the full sort instead of the hash buckets,
     KSP_HASH_GROUP=0; block lists by sorting the entries by block instead of key by key, KSP_KEY_GROUPS=0): as shipped (sources reordered by shared-key label, join over the
     work list of active tiles, accumulation chosen by the postings' sizes), with the caller's source
     order (KSP_REORDER=0), with the reordering but a plain walk over all tiles (KSP_NO_SCHED=1), and with
     the off-diagonal accumulation forced to the bit-sliced collect path / to the LDS counters."""
-    for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_HASH_GROUP", "KSP_KEY_GROUPS", "KSP_PARTITION"):
+    for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_HASH_GROUP", "KSP_KEY_GROUPS", "KSP_PARTITION", "KSP_JOIN"):
         monkeypatch.delenv(k, raising=False)
+    if request.param == "match_join":   # off-diagonal tiles from stage 1's match records instead of searching the lists
+        monkeypatch.setenv("KSP_JOIN", "matches")
     if request.param == "rocprim_partition":   # the library partition instead of partition_kernels.hip.h
         monkeypatch.setenv("KSP_PARTITION", "rocprim")
     if request.param == "sort_lists":

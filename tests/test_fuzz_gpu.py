@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 MODES = [{}, {"KSP_REORDER": "0"}, {"KSP_NO_SCHED": "1"}, {"KSP_COLLECT": "1"}, {"KSP_COLLECT": "0"},
          {"KSP_JOIN": "window"}, {"KSP_TAG32": "1"}, {"KSP_HASH_GROUP": "0"}, {"KSP_KEY_GROUPS": "0"},
-         {"KSP_KEY_GROUPS": "0", "KSP_REORDER": "0"}, {"KSP_PART_MIN": "1"}, {"KSP_PARTITION": "rocprim"}]
+         {"KSP_KEY_GROUPS": "0", "KSP_REORDER": "0"}, {"KSP_PART_MIN": "1"}, {"KSP_PARTITION": "rocprim"}, {"KSP_JOIN": "matches"}, {"KSP_JOIN": "matches", "KSP_COLLECT": "0"},
+         {"KSP_JOIN": "matches", "KSP_COLLECT": "1", "KSP_REORDER": "0"}]
 
 
 def _random_sketches(rng):

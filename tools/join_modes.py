@@ -7,9 +7,9 @@ from kspider_amd import engine, synth
 cfg = sys.argv[1]
 sk = synth.generate(cfg)
 dk = engine.DeviceBuffer.from_numpy(sk.keys)
-variants = [{}, {"KSP_COLLECT": "0"}, {"KSP_COLLECT": "1"}, {"KSP_NO_SCHED": "1"}, {"KSP_DEBUG_SHARES": "8"}, {"KSP_DEBUG_SHARES": "1"}]
+variants = [{}, {"KSP_JOIN": "search"}, {"KSP_JOIN": "matches"}, {"KSP_JOIN": "matches", "KSP_COLLECT": "0"}, {"KSP_JOIN": "matches", "KSP_COLLECT": "1"}]
 for env in variants:
-    for k in ("KSP_COLLECT", "KSP_NO_SCHED", "KSP_DEBUG_SHARES"):
+    for k in ("KSP_COLLECT", "KSP_NO_SCHED", "KSP_DEBUG_SHARES", "KSP_JOIN"):
         os.environ.pop(k, None)
     os.environ.update(env)
     e = engine.Engine(0)
