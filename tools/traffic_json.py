@@ -26,7 +26,10 @@ def kernel_source_hash():
 GROUPS = [  # (substring of the kernel name, group)
     ("k_max_last", "key range + source sizes"), ("k_src_size", "key range + source sizes"), ("k_iota4", "key range + source sizes"),
     ("k_tag", "tags + source sizes"),
-    ("k_part", "partition"), ("radix_sort_onesweep", "partition"), ("onesweep_histograms", "partition"),
+    ("k_zero_regions", "key range + source sizes"),
+    ("k_part", "partition"), ("k_hist2", "partition"), ("k_scan2", "partition"), ("k_scatter2", "partition"),
+    ("radix_sort_onesweep", "partition"), ("onesweep_histograms", "partition"),
+    ("k_match", "match records"),
     ("k_bucket", "bucket grouping"),
     ("k_label", "source labels + order"), ("k_perm", "source labels + order"), ("k_blk_bound", "source labels + order"),
     ("k_key_groups", "key groups"), ("k_group_totals", "key groups"),
