@@ -363,7 +363,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         }
         phase_mark(e, st, "key range + source sizes");
         hipLaunchKernelGGL(k_zero_regions, dim3(256), dim3(256), 0, st, z);
-        hipLaunchKernelGGL(k_max_last, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_keys, d_off, (unsigned long long*)scal, N);
+        hipLaunchKernelGGL(k_prep_sources, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_keys, d_off, (unsigned long long*)scal, sbound,
+                           iota, order, newidx, label, N);
     } else {
         KSP_HIP(hipMemsetAsync(scal + 4, 0, 8 * 11, st));   // [4] .. [14]: overflow words, counters of the partition
     }
@@ -384,8 +385,10 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if (!hand) phase_mark(e, st, "tags + source sizes");
     if ((W || e->nparts == 1) && !hand)   // (weighted slices still need the per-source weight sums of all entries)
         hipLaunchKernelGGL((k_tag<V, W>), dim3(N), dim3(256), 0, st, d_off, d_w, VA, sbound);
-    if (!W) hipLaunchKernelGGL(k_src_size, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_off, sbound, N);
-    hipLaunchKernelGGL(k_iota4, dim3(grid_for(N, bs)), dim3(bs), 0, st, iota, order, newidx, label, N);   // (order, newidx: identity until the labels are known)
+    if (!hand) {
+        if (!W) hipLaunchKernelGGL(k_src_size, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_off, sbound, N);
+        hipLaunchKernelGGL(k_iota4, dim3(grid_for(N, bs)), dim3(bs), 0, st, iota, order, newidx, label, N);   // (order, newidx: identity until the labels are known)
+    }
     if (!hand) KSP_HIP(hipMemsetAsync(e->blk_max.p, 0, ((size_t)nb + 1) * 4, st));
     if (!reorder) hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
     // slice mode (multi-GPU build): keep only the entries of this part's key range — one contiguous
@@ -437,7 +440,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     //  that use all 64 bits take the full-width sort.)
     const int shift = (e->full_sort || kbits >= 64) ? 0 : std::max(0, kbits - 32);
     u32* d_ovf = (u32*)(scal + 4);   // set by k_fix_runs when a run is too long; checked at the end of the build
-    KSP_HIP(hipMemsetAsync(d_ovf, 0, 8, st));
+    if (!hand) KSP_HIP(hipMemsetAsync(d_ovf, 0, 8, st));   // (the hand-written partition's build zeroes the scalar block at its start)
     tb = 0;
     // grouping by hash bucket (see k_bucket_group): partition on the top pb key bits only — buckets of
     // 400-800 entries for uniform hashes (up to twice that when the keys span just over half of [0, 2^kbits))
@@ -594,8 +597,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, label, labs, iota, order, (size_t)N, 0, lbits, st));
         if ((rc = e->tmp.ensure(tb))) return rc;
         KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, label, labs, iota, order, (size_t)N, 0, lbits, st));
-        hipLaunchKernelGGL(k_perm, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, newidx, N);
-        hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
+        hipLaunchKernelGGL(k_perm_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, newidx, sbound, e->blk_max.as<u32>(), N);
     }
     if (m == 0) return KSP_OK;
     e->have_rank_pairs = false;
@@ -619,7 +621,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         const u32 chunks = (u32)((m + KG_CHUNK - 1) / KG_CHUNK);
         phase_mark(e, st, "key groups");
         KSP_HIP(hipMemsetAsync(d_kovf, 0, 8, st));
-        KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input — are visited by no chunk)
+        if (phase == 3) KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input only — are visited by no chunk)
         hipLaunchKernelGGL((k_key_groups<V, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, rank1, firstp, newidx, (u32)m, U,
                            gsum, blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf,
                            std::getenv("KSP_DEBUG_COOP") ? std::max<u32>(KG_COOP, (u32)std::atoi(std::getenv("KSP_DEBUG_COOP"))) : KG_COOP,   // (timing experiments: raise the wave-per-key threshold)
@@ -660,8 +662,12 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
             if ((rc = e->tmp.ensure(tb))) return rc;
             KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
-            hipLaunchKernelGGL(k_blk_raw_groups, dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, sblk, (u32)e->h_scal[1], blk_raw, nb);
-            hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, blk_raw, blk_pos, scal, nb);
+            if (nb <= BRP_MAX) {
+                hipLaunchKernelGGL(k_blk_raw_pos, dim3(1), dim3(1024), 0, st, sblk, (u32)e->h_scal[1], blk_raw, blk_pos, scal, nb);
+            } else {
+                hipLaunchKernelGGL(k_blk_raw_groups, dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, sblk, (u32)e->h_scal[1], blk_raw, nb);
+                hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, blk_raw, blk_pos, scal, nb);
+            }
             hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
             hipLaunchKernelGGL((k_place_groups<W>), dim3(grid_for(K, bs)), dim3(bs), 0, st, sblk, sval, blk_raw, blk_pos, wkey,
                                e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, (u32)e->h_scal[1]);
@@ -1522,7 +1528,8 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     a.out_count = e->count.as<unsigned long long>();
     a.dbg = 0;
     if (const char* dbg = std::getenv("KSP_DEBUG_ABLATE")) a.dbg = (u32)std::atoi(dbg);
-    KSP_HIP(hipMemsetAsync(a.out_count, 0, 8, st));
+    ZeroList zj{};
+    zero_add(zj, a.out_count, 8);
     KSP_HIP(hipEventRecord(e->ev[2], st));
     dim3 block(JW * 64);
     a.blk_max = e->blk_max.as<u32>();
@@ -1561,8 +1568,11 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
             if ((rc = e->tailbuf.ensure(((size_t)nsplit * TB * TB + nsplit + 16) * 4))) return rc;
             a.tailbuf = e->tailbuf.as<u32>();
             a.tail_done = a.tailbuf + (size_t)nsplit * TB * TB;
-            KSP_HIP(hipMemsetAsync(a.tailbuf, 0, ((size_t)nsplit * TB * TB + nsplit + 16) * 4, st));
+            if (((size_t)nsplit * TB * TB + nsplit + 16) < (1ull << 30)) zero_add(zj, a.tailbuf, ((size_t)nsplit * TB * TB + nsplit + 16) * 4);
+            else KSP_HIP(hipMemsetAsync(a.tailbuf, 0, ((size_t)nsplit * TB * TB + nsplit + 16) * 4, st));
         }
+        hipLaunchKernelGGL(k_zero_regions, dim3(256), dim3(256), 0, st, zj);   // (the edge counter and the split tiles' buffers: one launch)
+        zj.n = 0;
         for (int pass = 0; pass < (e->need32 ? 2 : 1); ++pass)
             for (u64 w = wgA; w < wgB; w += kMaxTilesPerLaunch) {
                 a.wg0 = (u32)w;
@@ -1570,6 +1580,7 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
             }
         KSP_HIP(hipGetLastError());
     }
+    if (zj.n) { hipLaunchKernelGGL(k_zero_regions, dim3(1), dim3(64), 0, st, zj); zj.n = 0; }   // (dense mode: the edge counter)
     for (u64 chunk_begin = tile_begin; !e->sched_on && chunk_begin < tile_end; chunk_begin += kMaxTilesPerLaunch) {
     const u64 chunk_end = std::min(tile_end, chunk_begin + kMaxTilesPerLaunch);
     a.tile_begin = chunk_begin;

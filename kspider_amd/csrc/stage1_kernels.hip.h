@@ -47,6 +47,24 @@ __global__ void k_src_size(const u64* __restrict__ off, u32* __restrict__ src_bo
     if (s < n_sources) { const u64 c = off[s + 1] - off[s]; src_bound[s] = (u32)(c > 0xFFFFFFFFull ? 0xFFFFFFFFull : c); }
 }
 
+// everything a build needs per source before the partition, in one launch: the largest key (= largest last element
+// of the sorted runs), the bound of a source's pair counters (its size) and the four identity maps
+__global__ void k_prep_sources(const u64* __restrict__ keys, const u64* __restrict__ off, unsigned long long* __restrict__ max_out,
+                               u32* __restrict__ src_bound, u32* __restrict__ p0, u32* __restrict__ p1, u32* __restrict__ p2,
+                               u32* __restrict__ p3, u32 n_sources) {
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = 0;
+    if (s < n_sources) {
+        const u64 b = off[s], e = off[s + 1];
+        if (e > b) v = keys[e - 1];
+        const u64 c = e - b;
+        src_bound[s] = (u32)(c > 0xFFFFFFFFull ? 0xFFFFFFFFull : c);
+        p0[s] = s; p1[s] = s; p2[s] = s; p3[s] = s;
+    }
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned long long)__shfl_down(v, o));
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(max_out, v);
+}
+
 // ---- source reordering ---------------------------------------------------------------------
 // Sources that share keys are moved next to each other before they are cut into blocks: a source's
 // label is the smallest source id among the holders of any of its shared keys (one round of
@@ -113,6 +131,15 @@ __global__ void k_post_expand(const u32* __restrict__ koff, const u32* __restric
 __global__ void k_perm(const u32* __restrict__ order, u32* __restrict__ newidx, u32 n) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) newidx[order[i]] = i;
+}
+// both at once: newidx[order[i]] = i and the largest per-source bound of every block of the new order
+__global__ void k_perm_bound(const u32* __restrict__ order, u32* __restrict__ newidx, const u32* __restrict__ src_bound,
+                             u32* __restrict__ blk_max, u32 n) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 s = order[i];
+    newidx[s] = i;
+    atomicMax(&blk_max[i / TB], src_bound[s]);
 }
 template <class V>
 __global__ void k_retag(V* __restrict__ vals, const u32* __restrict__ newidx, u64 n) {
@@ -930,6 +957,31 @@ __global__ void k_blk_raw_groups(const u32* __restrict__ sblk, u32 n_groups, u32
         if (sblk[mid] < b) lo = mid + 1; else hi = mid;
     }
     blk_raw[b] = lo;
+}
+// k_blk_raw_groups + k_blk_pos in one workgroup (up to 1024 x 8 blocks): bisect, then the padded starts
+constexpr u32 BRP_MAX = 8192;
+__global__ __launch_bounds__(1024) void k_blk_raw_pos(const u32* __restrict__ sblk, u32 n_groups, u32* __restrict__ blk_raw,
+                                                      u32* __restrict__ blk_pos, u64* __restrict__ scal, u32 nb) {
+    __shared__ u32 s_raw[BRP_MAX + 1];
+    for (u32 b = threadIdx.x; b <= nb; b += blockDim.x) {
+        u32 lo = 0, hi = n_groups;
+        while (lo < hi) {
+            const u32 mid = lo + ((hi - lo) >> 1);
+            if (sblk[mid] < b) lo = mid + 1; else hi = mid;
+        }
+        s_raw[b] = lo;
+        blk_raw[b] = lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 pos = 0;
+        for (u32 b = 0; b < nb; ++b) {
+            blk_pos[b] = pos;
+            pos = ((pos + (s_raw[b + 1] - s_raw[b]) + 3u) & ~3u) + WIN;
+        }
+        blk_pos[nb] = pos;
+        scal[3] = pos;
+    }
 }
 // groups (sorted by block, ranks ascending inside a block) to the padded lists
 template <bool W>
