@@ -72,16 +72,16 @@ def build_blocks_sharded(eng, d_keys_ptr: int, h_offsets: np.ndarray, world_size
     bigstride = max(1, int(sizes[2::4].max()))
     weighted = d_weights_ptr != 0
 
-    def alloc(cols):
-        return torch.zeros((world_size, cols), dtype=torch.int32, device=device)
+    def alloc(cols):   # (every word that assemble reads is written by the exchange: no zero fill per step)
+        return torch.empty((world_size, cols), dtype=torch.int32, device=device)
 
     brk_all, info_all = alloc(lstride), alloc(lstride)
     bw_all = alloc(lstride) if weighted else None
     raw_all, pos_all, big_all = alloc(nb + 1), alloc(nb + 1), alloc(4 * bigstride)
-    loc = [torch.zeros(lstride, dtype=torch.int32, device=device), torch.zeros(lstride, dtype=torch.int32, device=device),
-           torch.zeros(lstride, dtype=torch.int32, device=device) if weighted else None,
+    loc = [torch.empty(lstride, dtype=torch.int32, device=device), torch.empty(lstride, dtype=torch.int32, device=device),
+           torch.empty(lstride, dtype=torch.int32, device=device) if weighted else None,
            torch.zeros(nb + 1, dtype=torch.int32, device=device), torch.zeros(nb + 1, dtype=torch.int32, device=device),
-           torch.zeros(4 * bigstride, dtype=torch.int32, device=device)]
+           torch.empty(4 * bigstride, dtype=torch.int32, device=device)]
     eng.slice_export(loc[0].data_ptr(), loc[1].data_ptr(), loc[2].data_ptr() if weighted else 0, loc[3].data_ptr(),
                      loc[4].data_ptr(), loc[5].data_ptr(), stream=stream)
     received = 0
