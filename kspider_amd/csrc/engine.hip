@@ -119,6 +119,8 @@ struct ksp_engine {
     bool part_off = false;        // the hand-written partition gave up on these keys (page tables full): rocPRIM partition
     u32 part_min = 4096;          // entries from which the hand-written partition is used (KSP_PART_MIN)
     ksp::Buf PK, PT, PD, parena;  // level-1 pages of the partition: keys, tags, digit bytes; pools, cursors, page tables
+    ksp::Buf PK2, PT2, PD2;       // pages of the middle level (more than 65 536 buckets)
+    ksp::Buf biglist;             // buckets above the LDS table's entry capacity (k_bucket_big)
     // phase timers (ksp_engine_set_profiling): events at the phase starts of the last build / join
     bool profiling = false;
     static constexpr int kMaxPhase = 24;
@@ -314,34 +316,65 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     // source tags itself: no read-back, no tagging pass.  Unweighted whole builds whose bucket count fits
     // its two levels; everything else (weighted sketches, key-range slices, > 2^16 buckets) takes the
     // rocPRIM partition below.
-    u32 nb_hand = 0;   // buckets of the hand-written partition (any number up to 2^16; 0: not used)
+    u32 nb_hand = 0;   // buckets of the hand-written partition (any number up to 2^21; above 2^16: three levels; 0: not used)
     if (!W && phase == 0 && e->nparts == 1 && !e->hash_off && !e->full_sort && !e->part_off && n >= e->part_min) {
         u32 mean = HB_HAND_MEAN;
-        if (const char* bm = std::getenv("KSP_DEBUG_BUCKET_MEAN")) mean = (u32)std::max(64, std::atoi(bm));   // (timing experiments)
+        if (const char* bm = std::getenv("KSP_DEBUG_BUCKET_MEAN")) mean = (u32)std::max(8, std::atoi(bm));   // (timing experiments; tests: tiny buckets force the middle level)
         u64 want = (n + mean - 1) / mean;
-        if (want > 65536 && (n + 65535) / 65536 <= HB_HAND_MEAN_MAX) want = 65536;   // (somewhat larger buckets rather than the library path)
-        if (want <= 65536) nb_hand = (u32)std::max<u64>(1, want);
+        if (want > 65536 && (n + 65535) / 65536 <= HB_HAND_MEAN_MAX && !std::getenv("KSP_DEBUG_BUCKET_MEAN"))
+            want = 65536;   // (somewhat larger buckets rather than a third level)
+        if (want <= (256u * 32u * 256u) && !(want > 65536 && std::getenv("KSP_DEBUG_NO_MID"))) nb_hand = (u32)std::max<u64>(1, want);
     }
     const bool hand = nb_hand > 0;
     e->pre_zeroed_work = e->pre_zeroed_bits = false;
-    // layout of the hand-written partition's arena (see the partition step below)
-    int hp_pb2 = 0;
-    u32 hp_nb1 = 0, hp_lists = 0, hp_ptw = 0, hp_pool_r = 0, hp_nchunks = 0;
-    size_t hp_pages = 0, hp_zero_words = 0;
+    // layout of the hand-written partition's arena (see the partition step below): level 1 (`A`), and for more than
+    // 65 536 buckets a middle level (`M`) between it and the final scatter
+    int hp_pb2 = 0, hp_pbm = 0;
+    u32 hp_nb1 = 0, hp_nchunks = 0, hp_ngroups = 0;
+    size_t hp_zero_words = 0, hp_pages_a = 0, hp_pages_m = 0;
+    PartLists hp_a{}, hp_m{};
+    u32 *hp_gcnt = nullptr, *hp_gbase = nullptr, *hp_src = nullptr;
     if (hand) {
-        while (((nb_hand + (1u << hp_pb2) - 1) >> hp_pb2) > 256) ++hp_pb2;
-        hp_nb1 = (nb_hand + (1u << hp_pb2) - 1) >> hp_pb2;
-        hp_lists = hp_nb1 * P1_R;
-        hp_ptw = (u32)std::min<u64>(P1_PTW_MAX, 16 * (((n / hp_lists) >> P1_PLOG) + 1) + 16);
-        const u64 per_r = n / P1_R;
-        hp_pool_r = (u32)((per_r >> P1_PLOG) + (per_r >> (P1_PLOG + 3)) + hp_nb1 + 8);   // pages per sub-list class
-        hp_pages = (size_t)hp_pool_r * P1_R;
+        if (nb_hand <= 65536) {
+            while (((nb_hand + (1u << hp_pb2) - 1) >> hp_pb2) > 256) ++hp_pb2;
+        } else {
+            // three levels: the middle one orders whole pages in LDS and writes long runs, so it takes as many bits as
+            // it can (up to 5) and level 1 — whose runs are a source's keys inside one bucket — as few as possible
+            hp_pb2 = 8;
+            const u32 pre = (nb_hand + 255u) >> 8;
+            while (hp_pbm < 5 && ((pre + (1u << hp_pbm) - 1) >> hp_pbm) > 64) ++hp_pbm;
+            while (((pre + (1u << hp_pbm) - 1) >> hp_pbm) > 256) ++hp_pbm;
+        }
+        const u32 prefixes = (nb_hand + (1u << hp_pb2) - 1) >> hp_pb2;           // groups of 2^pb2 final buckets
+        hp_nb1 = (prefixes + (1u << hp_pbm) - 1) >> hp_pbm;                         // level-1 buckets (<= 256)
+        hp_ngroups = hp_nb1 << hp_pbm;
+        auto plan = [&](PartLists& pl, const u32 buckets, const u32 subs, size_t& pages) {
+            const u32 lists = buckets * subs;
+            pl.subs = subs;
+            pl.ptw = (u32)std::min<u64>(P1_PTW_MAX, 8 * (((n / lists) >> P1_PLOG) + 1) + 16);
+            const u64 per = n / subs;
+            pl.pool_pages = (u32)((per >> P1_PLOG) + (per >> (P1_PLOG + 3)) + buckets + 8);   // pages per sub-list class
+            pages = (size_t)pl.pool_pages * subs;
+            return (size_t)subs * P1_LINE + (size_t)lists * P1_LINE + (size_t)lists * pl.ptw + pages;   // words, all zeroed per build
+        };
+        const size_t words_a = plan(hp_a, hp_nb1, P1_R, hp_pages_a);
+        const size_t words_m = hp_pbm ? plan(hp_m, hp_ngroups, 2, hp_pages_m) : 0;
         hp_nchunks = grid_for(n, P1_CH);
-        // arena (zeroed per build): pools and cursors (one line each), page tables, page owners, bucket counters |
-        // chunk sources
-        hp_zero_words = (size_t)P1_R * P1_LINE + (size_t)hp_lists * P1_LINE + (size_t)hp_lists * hp_ptw + hp_pages +
-                        ((size_t)nb_hand + 1);
-        if ((rc = e->parena.ensure((hp_zero_words + hp_nchunks + 2) * 4))) return rc;
+        // arena: [level 1 | middle level | bucket counters] zeroed per build, then group bases and chunk sources
+        hp_zero_words = words_a + words_m + ((size_t)nb_hand + 1);
+        if ((rc = e->parena.ensure((hp_zero_words + hp_ngroups + 2 + hp_nchunks + 2) * 4))) return rc;
+        auto carve = [&](PartLists& pl, u32* base, const u32 buckets) {
+            const size_t lists = (size_t)buckets * pl.subs;
+            pl.pools = base;
+            pl.cursors = pl.pools + (size_t)pl.subs * P1_LINE;
+            pl.pt = pl.cursors + lists * P1_LINE;
+            pl.owner = pl.pt + lists * pl.ptw;
+        };
+        carve(hp_a, e->parena.as<u32>(), hp_nb1);
+        if (hp_pbm) carve(hp_m, e->parena.as<u32>() + words_a, hp_ngroups);
+        hp_gcnt = e->parena.as<u32>() + words_a + words_m;
+        hp_gbase = hp_gcnt + ((size_t)nb_hand + 1);
+        hp_src = hp_gbase + (hp_ngroups + 2);
         // everything this build needs zeroed, in one launch: the scalar block, the per-block maxima, the partition's
         // arena, the bucket totals, and (small inputs) the diagonal work and the tile bitmap of the work list
         ZeroList z{};
@@ -466,30 +499,35 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         u32* bstart = (u32*)(bbase + nbuckets);   // nbuckets + 1
         u32* d_hovf = (u32*)(scal + 9);
         if (hand) {
-            // two-level partition by bucket = floor(key * nbuckets / (max key + 1)): d_keys -> pages -> KA, VB, bstart
-            const int pb2 = hp_pb2;
-            const u32 nb1 = hp_nb1, lists = hp_lists, ptw = hp_ptw, pool_r = hp_pool_r, nchunks = hp_nchunks;
-            const size_t pages = hp_pages;
-            if ((rc = e->PK.ensure(pages * P1_PAGE * 8))) return rc;
-            if ((rc = e->PT.ensure(pages * P1_PAGE * sizeof(V)))) return rc;
-            if ((rc = e->PD.ensure(pages * P1_PAGE))) return rc;
-            u32* pools = e->parena.as<u32>();
-            u32* cursors = pools + (size_t)P1_R * P1_LINE;
-            u32* ptab = cursors + (size_t)lists * P1_LINE;
-            u32* owner = ptab + (size_t)lists * ptw;
-            u32* gcur = owner + pages;
-            u32* src_tbl = gcur + ((size_t)nbuckets + 1);
+            // partition by bucket = floor(key * nbuckets / (max key + 1)): d_keys -> level-1 pages [-> middle pages] -> KA, VB, bstart
+            if ((rc = e->PK.ensure(hp_pages_a * P1_PAGE * 8))) return rc;
+            if ((rc = e->PT.ensure(hp_pages_a * P1_PAGE * sizeof(V)))) return rc;
+            if ((rc = e->PD.ensure(hp_pages_a * P1_PAGE))) return rc;
+            if (hp_pbm) {
+                if ((rc = e->PK2.ensure(hp_pages_m * P1_PAGE * 8))) return rc;
+                if ((rc = e->PT2.ensure(hp_pages_m * P1_PAGE * sizeof(V)))) return rc;
+                if ((rc = e->PD2.ensure(hp_pages_m * P1_PAGE))) return rc;
+            }
             phase_mark(e, st, "partition");
             KSP_HIP(hipEventRecord(e->ev[4], st));
-            hipLaunchKernelGGL(k_part_src, dim3(grid_for((u64)nchunks + 1, bs)), dim3(bs), 0, st, d_off, N, nchunks, src_tbl,
-                               scal, nbuckets);
-            hipLaunchKernelGGL((k_part1<V>), dim3(nchunks), dim3(P1_THREADS), 0, st, d_keys, d_off, N, (u32)nw, scal, pb2,
-                               nbuckets - 1, ptw, pools, cursors, ptab, pool_r, src_tbl, owner, e->PK.as<u64>(),
-                               e->PT.as<V>(), e->PD.as<u8>());
-            hipLaunchKernelGGL(k_hist2, dim3((u32)pages), dim3(256), 0, st, scal, cursors, owner, ptw, pb2, e->PD.as<u8>(), gcur);
-            hipLaunchKernelGGL(k_scan2, dim3(nb1), dim3(256), 0, st, scal, cursors, pb2, nbuckets, nb1, (u32)nw, gcur, bstart);
-            hipLaunchKernelGGL((k_scatter2<V>), dim3((u32)pages), dim3(P2_THREADS), 0, st, scal, cursors, owner, ptw, pb2,
-                               nbuckets - 1, e->PK.as<u64>(), e->PT.as<V>(), gcur, KA, VB);
+            hipLaunchKernelGGL(k_part_src, dim3(grid_for((u64)hp_nchunks + 1, bs)), dim3(bs), 0, st, d_off, N, hp_nchunks, hp_src, scal,
+                               nbuckets);
+            hipLaunchKernelGGL((k_part1<V>), dim3(hp_nchunks), dim3(P1_THREADS), 0, st, d_keys, d_off, N, (u32)nw, scal,
+                               hp_pb2 + hp_pbm, hp_pb2, nbuckets - 1, hp_a, hp_src, e->PK.as<u64>(), e->PT.as<V>(), e->PD.as<u8>());
+            if (hp_pbm)
+                hipLaunchKernelGGL((k_part_mid<V>), dim3((u32)hp_pages_a), dim3(P2_THREADS), 0, st, scal, hp_a, hp_m, hp_pb2, hp_pbm,
+                                   nbuckets - 1, e->PK.as<u64>(), e->PT.as<V>(), e->PD.as<u8>(), e->PK2.as<u64>(), e->PT2.as<V>(),
+                                   e->PD2.as<u8>());
+            const PartLists& last = hp_pbm ? hp_m : hp_a;
+            const size_t pages_last = hp_pbm ? hp_pages_m : hp_pages_a;
+            const u64* Kl = hp_pbm ? e->PK2.as<u64>() : e->PK.as<u64>();
+            const V* Tl = hp_pbm ? e->PT2.as<V>() : e->PT.as<V>();
+            const u8* Dl = hp_pbm ? e->PD2.as<u8>() : e->PD.as<u8>();
+            hipLaunchKernelGGL(k_hist2, dim3((u32)pages_last), dim3(256), 0, st, scal, last, hp_pb2, Dl, hp_gcnt);
+            hipLaunchKernelGGL(k_group_base, dim3(1), dim3(1024), 0, st, scal, last, hp_ngroups, (u32)nw, hp_gbase);
+            hipLaunchKernelGGL(k_scan2, dim3(hp_ngroups), dim3(256), 0, st, hp_gbase, hp_pb2, nbuckets, hp_ngroups, hp_gcnt, bstart);
+            hipLaunchKernelGGL((k_scatter2<V>), dim3((u32)pages_last), dim3(P2_THREADS), 0, st, scal, last, hp_pb2, nbuckets - 1, Kl, Tl,
+                               hp_gcnt, KA, VB);
             KSP_HIP(hipEventRecord(e->ev[5], st));
             phase_mark(e, st, "bucket grouping");   // (bsum: zeroed with the rest at the start of the build)
         } else {
@@ -514,10 +552,13 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             KSP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
             e->hb_slots = (u32)std::max(1, per_cu * cus);
         }
-        u32* big_list = bstart + (nbuckets + 1);   // buckets above HB_CAP entries (d_hovf[1] counts them)
+        // buckets above HB_CAP entries (d_hovf[1] counts them): a slot per bucket, so data whose keys have hundreds of
+        // holders each (C3: a third of the buckets at a mean of 2 000) stays on this path instead of falling back to the sort
+        if ((rc = e->biglist.ensure(((size_t)nbuckets + 1) * 4))) return rc;
+        u32* big_list = e->biglist.as<u32>();
         hipLaunchKernelGGL(k_bucket_group, dim3(std::min(nbuckets, e->hb_slots)), dim3(HB_THREADS), 0, st, KA, bstart,
                            nbuckets, (u32)nw, rec, bsum, d_hovf, big_list);
-        hipLaunchKernelGGL((k_bucket_big<V, 0>), dim3(128), dim3(HB_THREADS), 0, st, KA, VB, bstart, big_list, d_hovf,
+        hipLaunchKernelGGL((k_bucket_big<V, 0>), dim3(1024), dim3(HB_THREADS), 0, st, KA, VB, bstart, big_list, d_hovf,
                            bsum, (const u64*)nullptr, VA, rank1, first);
         size_t tb2 = 0;
         KSP_HIP(rocprim::exclusive_scan(nullptr, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
@@ -525,7 +566,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
         hipLaunchKernelGGL((k_bucket_emit<V>), dim3((nbuckets + HB_EMIT - 1) / HB_EMIT), dim3(HB_THREADS), 0, st, rec, VB, bstart,
                            bbase, bsum, nbuckets, VA, rank1, first, scal);
-        hipLaunchKernelGGL((k_bucket_big<V, 1>), dim3(128), dim3(HB_THREADS), 0, st, KA, VB, bstart, big_list, d_hovf,
+        hipLaunchKernelGGL((k_bucket_big<V, 1>), dim3(1024), dim3(HB_THREADS), 0, st, KA, VB, bstart, big_list, d_hovf,
                            bsum, bbase, VA, rank1, first);
         KSP_HIP(hipMemcpyAsync(e->h_scal, scal, 120, hipMemcpyDeviceToHost, st));   // [0] max key, [2] keys, [6] entries, [9] / [14] overflow (one copy)
         KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
@@ -888,7 +929,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
-                        &e->d_wg, &e->gp, &e->gm, &e->PK, &e->PT, &e->PD, &e->parena, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
+                        &e->d_wg, &e->gp, &e->gm, &e->PK, &e->PT, &e->PD, &e->parena, &e->PK2, &e->PT2, &e->PD2, &e->biglist, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
                         &e->mr0, &e->mr1, &e->mstart};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);

@@ -42,7 +42,7 @@ constexpr u32 P1_R = 8;           // sub-lists per level-1 bucket (one per XCD)
 constexpr u32 P1_LINE = 32;       // u32 words per cursor: a memory line of its own
 constexpr u32 P1_PLOG = 12;       // page = 4 096 entries
 constexpr u32 P1_PAGE = 1u << P1_PLOG;
-constexpr u32 P1_PTW_MAX = 128;   // page-table entries per sub-list
+constexpr u32 P1_PTW_MAX = 8192;  // page-table entries per sub-list (8 x the expected number + 16, at most this)
 constexpr u32 P2_THREADS = 512, P2_TILE = P1_PAGE, P2_EPT = P2_TILE / P2_THREADS;   // one page per workgroup
 
 // control words inside the engine's scalar block (u64 units): [0] largest key (k_max_last),
@@ -96,6 +96,41 @@ __device__ inline u32 part_wait_page(u32* __restrict__ pt, const u32 row, const 
     return ~0u;
 }
 
+// One paged level of the partition: `subs` sub-lists per bucket (list = bucket * subs + sub), each a sequence of
+// pages drawn from the pool of its sub-list class.
+struct PartLists {
+    u32* pools;      // `subs` page counters, one memory line each
+    u32* cursors;    // entries reserved so far, one memory line per list
+    u32* pt;         // lists x ptw: physical page + 1 (0: not allocated yet)
+    u32* owner;      // per physical page: list * ptw + index in the list's page table + 1 (0: unused)
+    u32 ptw, pool_pages, subs;
+};
+// reserve `cnt` (1 .. 4096) consecutive places in list L: v = first place; g0 / g1 = physical pages of the first and
+// the last place (~0 after an overflow).  The reservation that covers a page's first place allocates that page and
+// publishes it BEFORE it waits for anything.
+__device__ inline void part_reserve(const PartLists& pl, const u32 L, const u32 sub, const u32 cnt, u32* __restrict__ ovf, u32& v,
+                                    u32& g0, u32& g1) {
+    v = atomicAdd(&pl.cursors[(size_t)L * P1_LINE], cnt);
+    const u32 q0 = v >> P1_PLOG, q1 = (v + cnt - 1) >> P1_PLOG;
+    const u32 mine = (v & (P1_PAGE - 1)) == 0 ? q0 : (q1 != q0 ? q1 : ~0u);
+    if (mine != ~0u) {
+        bool ok = false;
+        if (mine < pl.ptw) {
+            const u32 ph = atomicAdd(&pl.pools[(size_t)sub * P1_LINE], 1u);
+            if (ph < pl.pool_pages) {
+                pl.owner[sub * pl.pool_pages + ph] = L * pl.ptw + mine + 1;   // (read by the next level, after this kernel)
+                __hip_atomic_store(&pl.pt[(size_t)L * pl.ptw + mine], sub * pl.pool_pages + ph + 1, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                ok = true;
+            }
+        }
+        if (!ok) __hip_atomic_store(ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("" ::: "memory");   // (every lane has published its page before any lane starts to wait)
+    g0 = part_wait_page(pl.pt, L * pl.ptw, q0, pl.ptw, ovf);
+    g1 = q1 == q0 ? g0 : part_wait_page(pl.pt, L * pl.ptw, q1, pl.ptw, ovf);
+}
+
 // source of the first entry of every chunk (tbl[nchunks] = the last source): the bisection is done once, by a
 // kernel of its own, instead of sitting at the start of every chunk's critical path
 __global__ void k_part_src(const u64* __restrict__ off, const u32 n_sources, const u32 nchunks, u32* __restrict__ tbl,
@@ -109,11 +144,9 @@ __global__ void k_part_src(const u64* __restrict__ off, const u32 n_sources, con
 template <class V>
 __global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ keys, const u64* __restrict__ off,
                                                       const u32 n_sources, const u32 n, u64* __restrict__ scal,
-                                                      const int pb2, const u32 nbm1, const u32 ptw,
-                                                      u32* __restrict__ pools, u32* __restrict__ cursors,
-                                                      u32* __restrict__ pt, const u32 pool_pages,
-                                                      const u32* __restrict__ src_tbl, u32* __restrict__ owner,
-                                                      u64* __restrict__ Kp, V* __restrict__ Tp, u8* __restrict__ Dp) {
+                                                      const int sh1, const int pb2, const u32 nbm1, const PartLists pl,
+                                                      const u32* __restrict__ src_tbl, u64* __restrict__ Kp,
+                                                      V* __restrict__ Tp, u8* __restrict__ Dp) {
     __shared__ __attribute__((aligned(16))) u32 s_src[P1_CH];
     __shared__ u32 s_hist[256], s_base[256], s_pg0[256], s_pg1[256];
     __shared__ u32 s_wmax[P1_THREADS / 64];
@@ -127,8 +160,8 @@ __global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ ke
     }
     const u64 mult = scal[PC_MULT];
     const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
-    const u32 rsub = blockIdx.x & (P1_R - 1);                 // sub-list class: workgroups b and b + 8 share an XCD
-    u32* const pool = pools + (size_t)rsub * P1_LINE;         // (one page pool per class: a single word would see
+    const u32 rsub = blockIdx.x & (pl.subs - 1);              // sub-list class: workgroups b and b + 8 share an XCD
+                                                              // (one page pool per class: a single word would see
                                                               //  every page allocation of the launch)
     u32* const ovf = reinterpret_cast<u32*>(scal + PC_OVF);
     if (tid < 256) s_hist[tid] = 0;
@@ -168,7 +201,7 @@ __global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ ke
         const u32 idx = j * P1_THREADS + tid;
         const bool valid = idx < cn;
         const u32 b = part_bucket(key[j], mult, ident, nbm1);
-        const u32 d1 = valid ? (b >> pb2) : 0x1FFu, d2 = b & ((1u << pb2) - 1u);
+        const u32 d1 = valid ? (b >> sh1) : 0x1FFu, d2 = b & ((1u << pb2) - 1u);
         const u32 prev = __shfl_up(d1, 1);
         const bool head = lane == 0 || prev != d1;
         const unsigned long long hm = __ballot(head);
@@ -185,28 +218,7 @@ __global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ ke
     if (tid < 256) {   // one reservation per (workgroup, level-1 bucket); the one that crosses a page start allocates the page
         const u32 cnt = s_hist[tid];
         u32 v = 0, g0 = ~0u, g1 = ~0u;
-        if (cnt) {
-            const u32 L = tid * P1_R + rsub;
-            v = atomicAdd(&cursors[(size_t)L * P1_LINE], cnt);
-            const u32 q0 = v >> P1_PLOG, q1 = (v + cnt - 1) >> P1_PLOG;
-            const u32 mine = (v & (P1_PAGE - 1)) == 0 ? q0 : (q1 != q0 ? q1 : ~0u);
-            if (mine != ~0u) {
-                bool ok = false;
-                if (mine < ptw) {
-                    const u32 ph = atomicAdd(pool, 1u);
-                    if (ph < pool_pages) {
-                        owner[rsub * pool_pages + ph] = L * ptw + mine + 1;   // (read by level 2, after this kernel)
-                        __hip_atomic_store(&pt[(size_t)L * ptw + mine], rsub * pool_pages + ph + 1, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                        ok = true;
-                    }
-                }
-                if (!ok) __hip_atomic_store(ovf, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("" ::: "memory");   // (every lane has published its page before any lane starts to wait)
-            g0 = part_wait_page(pt, L * ptw, q0, ptw, ovf);
-            g1 = q1 == q0 ? g0 : part_wait_page(pt, L * ptw, q1, ptw, ovf);
-        }
+        if (cnt) part_reserve(pl, tid * pl.subs + rsub, rsub, cnt, ovf, v, g0, g1);
         s_base[tid] = v; s_pg0[tid] = g0; s_pg1[tid] = g1;
     }
     __syncthreads();
@@ -227,13 +239,12 @@ __global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ ke
 
 // level 2, counting: one workgroup per page — entries per final bucket from the page's 4 096 digit bytes
 // (an LDS histogram, then one global add per bucket present).  gcnt is zero at launch.
-__global__ __launch_bounds__(256) void k_hist2(const u64* __restrict__ scal, const u32* __restrict__ cursors,
-                                               const u32* __restrict__ owner, const u32 ptw, const int pb2,
+__global__ __launch_bounds__(256) void k_hist2(const u64* __restrict__ scal, const PartLists pl, const int pb2,
                                                const u8* __restrict__ Dp, u32* __restrict__ gcnt) {
     __shared__ u32 s_hist[256];
-    const u32 ow = owner[blockIdx.x];
+    const u32 ow = pl.owner[blockIdx.x];
     if (!ow || reinterpret_cast<const u32*>(scal + PC_OVF)[0]) return;   // (after an overflow: nothing is counted, every bucket stays empty)
-    const u32 L = (ow - 1) / ptw, q = (ow - 1) % ptw, len = cursors[(size_t)L * P1_LINE];
+    const u32 L = (ow - 1) / pl.ptw, q = (ow - 1) % pl.ptw, len = pl.cursors[(size_t)L * P1_LINE];
     if (len <= (q << P1_PLOG)) return;
     const u32 m = min(P1_PAGE, len - (q << P1_PLOG)), tid = threadIdx.x;
     s_hist[tid] = 0;
@@ -248,25 +259,46 @@ __global__ __launch_bounds__(256) void k_hist2(const u64* __restrict__ scal, con
     }
     __syncthreads();
     const u32 c = s_hist[tid];
-    if (c) atomicAdd(&gcnt[((L / P1_R) << pb2) + tid], c);
+    if (c) atomicAdd(&gcnt[((L / pl.subs) << pb2) + tid], c);
 }
 
-// the exact start of every final bucket in the dense output: one workgroup per level-1 bucket B sums the lists in
-// front of it (every entry was counted exactly once by its list's cursor) and scans its own <= 256 buckets.
-// Writes bstart (what k_bucket_bounds used to search for) and turns gcnt into the cursors of the scatter.
-__global__ __launch_bounds__(256) void k_scan2(u64* __restrict__ scal, const u32* __restrict__ cursors, const int pb2,
-                                               const u32 nbuckets, const u32 nb1, const u32 n, u32* __restrict__ gcnt,
-                                               u32* __restrict__ bstart) {
-    __shared__ u32 s_w[4], s_base;
-    const u32 B = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// entries in front of every bucket prefix (= group of `subs` lists of the last paged level): one workgroup, exclusive
+// scan of the groups' totals; gbase[ngroups] = all entries (every entry was counted exactly once by its list's cursor)
+__global__ __launch_bounds__(1024) void k_group_base(u64* __restrict__ scal, const PartLists pl, const u32 ngroups, const u32 n,
+                                                     u32* __restrict__ gbase) {
+    __shared__ u32 s_w[16], s_carry;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const bool bad = reinterpret_cast<const u32*>(scal + PC_OVF)[0] != 0;
-    u32 before = 0;   // entries of the level-1 buckets in front of B
-    for (u32 L = tid; L < B * P1_R; L += 256) before += bad ? 0u : cursors[(size_t)L * P1_LINE];
-    for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
-    if (lane == 0) s_w[wv] = before;
+    if (tid == 0) s_carry = 0;
     __syncthreads();
-    if (tid == 0) s_base = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    __syncthreads();
+    for (u32 g0 = 0; g0 < ngroups; g0 += 1024) {
+        const u32 g = g0 + tid;
+        u32 tot = 0;
+        if (g < ngroups && !bad)
+            for (u32 r = 0; r < pl.subs; ++r) tot += pl.cursors[(size_t)(g * pl.subs + r) * P1_LINE];
+        u32 inc = tot;
+        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        u32 run = s_carry + inc - tot;
+        for (u32 w = 0; w < wv; ++w) run += s_w[w];
+        if (g < ngroups) gbase[g] = run;
+        __syncthreads();
+        if (tid == 1023) s_carry = run + tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        gbase[ngroups] = s_carry;
+        if (!bad && s_carry != n) reinterpret_cast<u32*>(scal + PC_OVF)[0] = 2;   // (cannot happen: a defect, reported as such)
+    }
+}
+
+// the exact start of every final bucket in the dense output: one workgroup per bucket prefix scans its <= 256
+// buckets.  Writes bstart (what k_bucket_bounds used to search for) and turns gcnt into the cursors of the scatter.
+__global__ __launch_bounds__(256) void k_scan2(const u32* __restrict__ gbase, const int pb2, const u32 nbuckets, const u32 ngroups,
+                                               u32* __restrict__ gcnt, u32* __restrict__ bstart) {
+    __shared__ u32 s_w[4];
+    const u32 B = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 b = (B << pb2) + tid;
     const bool in = tid < (1u << pb2) && b < nbuckets;
     const u32 c = in ? gcnt[b] : 0u;
@@ -274,20 +306,15 @@ __global__ __launch_bounds__(256) void k_scan2(u64* __restrict__ scal, const u32
     for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
-    u32 run = s_base + inc - c;
+    u32 run = gbase[B] + inc - c;
     for (u32 w = 0; w < wv; ++w) run += s_w[w];
     if (in) { bstart[b] = run; gcnt[b] = run; }
-    if (B == nb1 - 1 && tid == 255) {
-        const u32 total = run + c;   // (thread 255 holds the inclusive sum over the whole workgroup: the grand total)
-        bstart[nbuckets] = total;
-        if (!bad && total != n) reinterpret_cast<u32*>(scal + PC_OVF)[0] = 2;   // (cannot happen: a defect, reported as such)
-    }
+    if (B == ngroups - 1 && tid == 0) bstart[nbuckets] = gbase[ngroups];
 }
 
 // level 2, scatter: one workgroup per page.  owner[page] = (sub-list, index in its page table) + 1, 0 = unused.
 template <class V>
-__global__ __launch_bounds__(P2_THREADS) void k_scatter2(const u64* __restrict__ scal, const u32* __restrict__ cursors,
-                                                         const u32* __restrict__ owner, const u32 ptw, const int pb2,
+__global__ __launch_bounds__(P2_THREADS) void k_scatter2(const u64* __restrict__ scal, const PartLists pl, const int pb2,
                                                          const u32 nbm1, const u64* __restrict__ Kp,
                                                          const V* __restrict__ Tp, u32* __restrict__ gcur,
                                                          u64* __restrict__ K2, V* __restrict__ T2) {
@@ -295,12 +322,12 @@ __global__ __launch_bounds__(P2_THREADS) void k_scatter2(const u64* __restrict__
     __shared__ V s_tag[P2_TILE];
     __shared__ u8 s_bin[P2_TILE];
     __shared__ u32 s_ls[256], s_cnt[256], s_gb[256];
-    const u32 ow = owner[blockIdx.x];
+    const u32 ow = pl.owner[blockIdx.x];
     if (!ow || reinterpret_cast<const u32*>(scal + PC_OVF)[0]) return;   // (after an overflow the build is repeated)
-    const u32 L = (ow - 1) / ptw, q = (ow - 1) % ptw, len = cursors[(size_t)L * P1_LINE];
+    const u32 L = (ow - 1) / pl.ptw, q = (ow - 1) % pl.ptw, len = pl.cursors[(size_t)L * P1_LINE];
     if (len <= (q << P1_PLOG)) return;
     const u32 m = min(P1_PAGE, len - (q << P1_PLOG));
-    const u32 B = L / P1_R, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 B = L / pl.subs, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 nb2m1 = (1u << pb2) - 1u;
     const u64 mult = scal[PC_MULT];
     const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
@@ -355,6 +382,97 @@ __global__ __launch_bounds__(P2_THREADS) void k_scatter2(const u64* __restrict__
             const u32 bin = s_bin[i], dst = s_gb[bin] + (i - s_ls[bin]);
             K2[dst] = s_key[i];
             T2[dst] = s_tag[i];
+        }
+    }
+}
+
+// middle level (sets of more than 65 536 buckets): one workgroup per level-1 page.  The page is ordered by the next
+// `pbm` bits of the bucket id in LDS, every group of entries reserves its run in the list of its (level-1 bucket,
+// middle digit) — pages from a second pool, same reservation as level 1 — and the runs (~4 096 / 2^pbm entries)
+// are written out: keys, tags and digit bytes.  The final level then works on these pages.
+template <class V>
+__global__ __launch_bounds__(P2_THREADS) void k_part_mid(const u64* __restrict__ scal, const PartLists pa, const PartLists pm,
+                                                         const int pb2, const int pbm, const u32 nbm1,
+                                                         const u64* __restrict__ Ka, const V* __restrict__ Ta,
+                                                         const u8* __restrict__ Da, u64* __restrict__ Km,
+                                                         V* __restrict__ Tm, u8* __restrict__ Dm) {
+    __shared__ u64 s_key[P2_TILE];
+    __shared__ V s_tag[P2_TILE];
+    __shared__ u8 s_dig[P2_TILE], s_bin[P2_TILE];
+    __shared__ u32 s_ls[256], s_cnt[256], s_v[256], s_g0[256], s_g1[256];
+    const u32 ow = pa.owner[blockIdx.x];
+    u32* const ovf = const_cast<u32*>(reinterpret_cast<const u32*>(scal + PC_OVF));
+    if (!ow || *ovf) return;
+    const u32 L = (ow - 1) / pa.ptw, q = (ow - 1) % pa.ptw, len = pa.cursors[(size_t)L * P1_LINE];
+    if (len <= (q << P1_PLOG)) return;
+    const u32 m = min(P1_PAGE, len - (q << P1_PLOG));
+    const u32 BA = L / pa.subs, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 nmid = 1u << pbm, sub = blockIdx.x & (pm.subs - 1);
+    const u64 mult = scal[PC_MULT];
+    const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
+    const size_t page = (size_t)blockIdx.x << P1_PLOG;
+    u64 key[P2_EPT];
+    V tag[P2_EPT];
+    u32 rk[P2_EPT], dig[P2_EPT];
+#pragma unroll
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        key[k] = 0; tag[k] = V(0); dig[k] = 0;
+        if (i < m) {
+            key[k] = __builtin_nontemporal_load(Ka + page + i);
+            tag[k] = __builtin_nontemporal_load(Ta + page + i);
+            dig[k] = Da[page + i];
+        }
+    }
+    if (tid < 256) s_cnt[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        rk[k] = (part_bucket(key[k], mult, ident, nbm1) >> pb2) & (nmid - 1);
+        if (i < m) rk[k] |= atomicAdd(&s_cnt[rk[k]], 1u) << 8;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        u32 c[4], t = 0;
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) { c[i] = s_cnt[4 * lane + i]; t += c[i]; }
+        u32 inc = t;
+        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+        u32 run = inc - t;
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) { s_ls[4 * lane + i] = run; run += c[i]; }
+    } else if (tid - 64 < 256) {   // one reservation per middle digit present in the page
+        const u32 bin = tid - 64, c = s_cnt[bin];
+        u32 v = 0, g0 = ~0u, g1 = ~0u;
+        if (c) part_reserve(pm, ((BA << pbm) | bin) * pm.subs + sub, sub, c, ovf, v, g0, g1);
+        s_v[bin] = v; s_g0[bin] = g0; s_g1[bin] = g1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        if (i < m) {
+            const u32 bin = rk[k] & 0xFFu, slot = s_ls[bin] + (rk[k] >> 8);
+            s_key[slot] = key[k];
+            s_tag[slot] = tag[k];
+            s_dig[slot] = (u8)dig[k];
+            s_bin[slot] = (u8)bin;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        if (i < m) {
+            const u32 bin = s_bin[i], base = s_v[bin], v = base + (i - s_ls[bin]);
+            const u32 ph = (v >> P1_PLOG) == (base >> P1_PLOG) ? s_g0[bin] : s_g1[bin];
+            if (ph != ~0u) {
+                const size_t a = ((size_t)ph << P1_PLOG) | (v & (P1_PAGE - 1));
+                Km[a] = s_key[i];
+                Tm[a] = s_tag[i];
+                Dm[a] = s_dig[i];
+            }
         }
     }
 }

@@ -327,7 +327,7 @@ constexpr u32 HB_MEAN = 800;
 constexpr u32 HB_HAND_MEAN = 2000, HB_HAND_MEAN_MAX = 2400;
 constexpr u32 HB_KEPT = 1u << 31, HB_FIRST = 1u << 30;   // per-entry record: kept | first of its key | rank << 12 | place
 constexpr u32 HB_EMIT = 8;       // buckets per workgroup of the emit kernel
-constexpr u32 HB_BIG_CAP = 1024, HB_BIG_DISTINCT = 3072;   // k_bucket_big: buckets per build / distinct keys per bucket
+constexpr u32 HB_BIG_DISTINCT = 3072;   // k_bucket_big: distinct keys per oversize bucket (any number of such buckets: the list holds one slot per bucket)
 
 __global__ void k_bucket_bounds(const u64* __restrict__ keys, u64 n, int shiftb, u32 nbuckets, u32* __restrict__ bstart) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
     while (b < nbuckets && b0 < nw) {   // (b0 == nw: this bucket and every later one is empty)
         if (raw > HB_CAP && tid == 0) {   // left to k_bucket_big (overflow[1] counts them)
             const u32 q = atomicAdd(&overflow[1], 1u);
-            if (q < HB_BIG_CAP) big_list[q] = b; else overflow[0] = 1;
+            big_list[q] = b;   // (one slot per bucket: cannot overflow)
         }
         const u32 bn = b + gridDim.x;
         u32 n0 = nw, nraw = 0;          // bounds of the next bucket
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict
     __shared__ unsigned long long tkey[HB_SLOTS + 1];
     __shared__ u32 tcnt[HB_SLOTS + 1], toff[HB_SLOTS + 1], trank[HB_SLOTS + 1], tfill[HB_SLOTS + 1];
     __shared__ u32 wpe[NWV], wpk[NWV], s_distinct;
-    const u32 n_big = min(overflow[1], HB_BIG_CAP);
+    const u32 n_big = overflow[1];
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (u32 q = blockIdx.x; q < n_big; q += gridDim.x) {   // (a few workgroups walk the list: it is empty for most inputs)
     const u32 b = big_list[q];

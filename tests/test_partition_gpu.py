@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _edges(sk, monkeypatch, **env):
-    for k in ("KSP_PARTITION", "KSP_PART_MIN"):
+    for k in ("KSP_PARTITION", "KSP_PART_MIN", "KSP_DEBUG_BUCKET_MEAN"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -111,3 +111,23 @@ def test_rebuilds_on_one_engine_give_the_same_edges(monkeypatch):
         if first is None:
             first = ev
         assert len(ev) == len(first) and (ev == first).all()
+
+
+def test_three_levels_when_there_are_more_than_65536_buckets(oracle_lib, monkeypatch):
+    """Sets above 1.3e8 entries (C3, C4) get a middle level between the level-1 lists and the final scatter; tiny
+    buckets force it on a set the brute-force oracle can check."""
+    rng = np.random.default_rng(17)
+    pool = rng.integers(0, (1 << 64) // 1000, size=300_000, dtype=np.uint64)
+    runs = []
+    for s in range(900):
+        fam = pool[(s % 6) * 50_000:(s % 6 + 1) * 50_000]
+        runs.append(np.unique(np.concatenate([fam[rng.random(fam.size) < 0.025],
+                                              rng.integers(0, (1 << 64) // 1000, size=int(rng.integers(1, 900)), dtype=np.uint64)])))
+    sk = synth.from_runs(runs)
+    assert int(sk.offsets[-1]) > 1_200_000                      # / 16 per bucket: > 65 536 buckets
+    ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
+    for mean in ("16", "9"):
+        hand, st = _edges(sk, monkeypatch, KSP_PART_MIN="1", KSP_DEBUG_BUCKET_MEAN=mean)
+        assert st["partition_kind"] == 2 and st["partition_fallback"] == 0, st
+        assert st["sort_bits"] > 16                                 # more than 2^16 buckets
+        assert len(hand) == len(ref) and (hand == ref).all()
