@@ -39,7 +39,8 @@ typedef struct ksp_engine ksp_engine;
 typedef struct ksp_stats {
     uint64_t n_sources;
     uint64_t n_entries;     /* sum of sketch sizes                                  */
-    uint64_t n_blocks;      /* ceil(n_sources / 128)                                */
+    uint64_t n_blocks;      /* blocks of 128 source slots: ceil(n_sources / 128), or up to half as many again when the
+                               source reordering keeps clusters inside blocks (slots without a source stay empty) */
     uint64_t n_block_keys;  /* distinct keys summed over blocks                     */
     uint64_t n_tiles;       /* n_blocks (n_blocks + 1) / 2                          */
     uint64_t last_tiles;    /* tiles joined by the last ksp_engine_join             */
@@ -66,6 +67,8 @@ typedef struct ksp_stats {
     uint64_t n_match_records;   /* match-list join: (key, block pair) records stage 1 handed to the join (0: the
                                    join searches the block lists)                                         */
     uint64_t n_join_workgroups; /* shares of the work list (workgroups of a join over all tiles)           */
+    uint64_t n_kept_entries;    /* entries whose key is held by at least two sources (the others are pruned) */
+    uint64_t n_kept_keys;       /* distinct keys among them                                                */
 } ksp_stats;
 
 const char* ksp_last_error(void);

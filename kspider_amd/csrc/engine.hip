@@ -99,6 +99,8 @@ struct ksp_engine {
     int device = 0;
     // inputs / geometry
     u32 n_sources = 0, nb = 0;
+    bool padded = false;          // nb holds spare blocks: block boundaries respect the clusters, some slots are holes (k_pack_blocks)
+    std::vector<u32> h_blk_src;   // nb + 1: sources in the blocks before block b (= b x 128 without holes)
     u64 n_entries = 0;
     u64 n_kept = 0;               // entries whose key is held by >= 2 sources (the others are pruned)
     bool weighted = false;
@@ -178,6 +180,22 @@ namespace ksp {
 
 static inline unsigned grid_for(u64 n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
 
+// Blocks of a build.  With the source reordering on, half as many again as the sources need: the spare slots let
+// clusters of up to 128 related sources start a block instead of straddling two (k_pack_blocks); what is not needed
+// stays empty (blocks without keys cost nothing).  Every engine that builds the same source set gets the same count.
+static u32 blocks_for(const u32 n_sources, const bool reorder) {
+    const u32 nb0 = (n_sources + TB - 1) / TB;
+    const char* al = std::getenv("KSP_ALIGN");   // 0: plain cuts every 128 sources (diagnostic / tests)
+    if (!reorder || n_sources <= (u32)TB || n_sources > PACK_MAX || (al && std::atoi(al) == 0)) return nb0;
+    u32 nb = nb0 + nb0 / 2 + 1;
+    if (n_sources <= 65536u) nb = std::max(nb0, std::min<u32>(nb, 65536u / TB));   // (16-bit entry tags hold block < 512)
+    return nb;
+}
+// stride of the per-source / per-slot maps in smap
+static size_t smap_stride(const ksp_engine* e) {
+    return (std::max<size_t>(e->n_sources, (size_t)e->nb * TB) + 64) & ~(size_t)63;
+}
+
 // start of a phase of stage 1 / the join (only with ksp_engine_set_profiling: an event per phase start)
 static inline void phase_mark(ksp_engine* e, hipStream_t st, const char* name) {
     if (!e->profiling || e->ph_n >= ksp_engine::kMaxPhase) return;
@@ -254,7 +272,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if ((rc = e->blk_raw.ensure(((size_t)nb + 2) * 4))) return rc;
     if ((rc = e->blk_pos.ensure(((size_t)nb + 2) * 4))) return rc;
     if ((rc = e->part.ensure(((size_t)nb + 1) * ((size_t)e->ncell + 1) * 4))) return rc;
-    if ((rc = e->blk_max.ensure(((size_t)nb + 2) * 4))) return rc;
+    if ((rc = e->blk_max.ensure((2 * (size_t)nb + 4) * 4))) return rc;
     if ((rc = e->scalars.ensure(128))) return rc;
     if ((rc = e->R1.ensure((n + 4) * 4))) return rc;
 
@@ -268,12 +286,14 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     u32* blk_pos = e->blk_pos.as<u32>();
     const unsigned bs = 256;
     u32* rank1 = e->R1.as<u32>();
-    const size_t NN = ((size_t)N + 64) & ~(size_t)63;
-    if ((rc = e->smap.ensure(6 * NN * 4))) return rc;
-    // per-source maps: [0] label, [1] iota, [2] sorted labels, [3] order (= engine index -> source id),
-    // [4] newidx (source id -> engine index), [5] bound of a source's pair counters
+    const size_t NN = smap_stride(e);
+    if ((rc = e->smap.ensure(7 * NN * 4))) return rc;
+    // per-source maps: [0] label, [1] iota, [2] sorted labels, [3] order (= engine index -> source id; ~0: a hole),
+    // [4] newidx (source id -> engine index), [5] bound of a source's pair counters, [6] sources in (label, id) order
     u32* sm = e->smap.as<u32>();
     u32 *label = sm, *iota = sm + NN, *labs = sm + 2 * NN, *order = sm + 3 * NN, *newidx = sm + 4 * NN, *sbound = sm + 5 * NN;
+    u32* sorted_src = sm + 6 * NN;
+    u32* blk_src = e->blk_max.as<u32>() + ((size_t)nb + 1);   // (behind the per-block maxima: one staging copy for both)
     const bool reorder = e->reorder;
     u32 label_max = std::max<u32>(256, N / 16);   // holders above which a key is ignored by the label pass
     if (const char* lm = std::getenv("KSP_DEBUG_LABEL_MAX")) label_max = (u32)std::max(1, std::atoi(lm));
@@ -635,10 +655,17 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         int lbits = 1;
         while (lbits < 32 && (N >> lbits)) ++lbits;
         tb = 0;
-        KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, label, labs, iota, order, (size_t)N, 0, lbits, st));
+        u32* sort_out = e->padded ? sorted_src : order;
+        KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, label, labs, iota, sort_out, (size_t)N, 0, lbits, st));
         if ((rc = e->tmp.ensure(tb))) return rc;
-        KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, label, labs, iota, order, (size_t)N, 0, lbits, st));
-        hipLaunchKernelGGL(k_perm_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, newidx, sbound, e->blk_max.as<u32>(), N);
+        KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, label, labs, iota, sort_out, (size_t)N, 0, lbits, st));
+        if (e->padded) {   // block boundaries at cluster boundaries where the spare slots allow
+            hipLaunchKernelGGL(k_pack_blocks, dim3(1), dim3(1024), 0, st, labs, N, nb, blk_src);
+            hipLaunchKernelGGL(k_place_sources, dim3(grid_for((u64)nb * TB, bs)), dim3(bs), 0, st, sorted_src, blk_src, newidx, order,
+                               sbound, e->blk_max.as<u32>(), nb);
+        } else {
+            hipLaunchKernelGGL(k_perm_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, newidx, sbound, e->blk_max.as<u32>(), N);
+        }
     }
     if (m == 0) return KSP_OK;
     e->have_rank_pairs = false;
@@ -1060,6 +1087,8 @@ static int build_schedule(ksp_engine* e) {
     e->sched_on = true;
     e->st.n_active_tiles = A;
     e->st.n_match_records = e->matches_on ? e->n_matches : 0;
+    e->st.n_kept_entries = e->n_kept;
+    e->st.n_kept_keys = e->h_scal_keys;
     e->st.n_join_workgroups = wg.size();
     return KSP_OK;
 }
@@ -1069,14 +1098,15 @@ static int build_schedule(ksp_engine* e) {
 // finish_build then reads them without a copy of its own)
 static int stage_block_tables(ksp_engine* e, hipStream_t st) {
     const size_t bytes = ((size_t)e->nb + 1) * 4;
-    if (e->h_blk_stage_bytes < 2 * bytes) {
+    if (e->h_blk_stage_bytes < 3 * bytes) {
         if (e->h_blk_stage) (void)hipHostFree(e->h_blk_stage);
         e->h_blk_stage = nullptr; e->h_blk_stage_bytes = 0;
-        KSP_HIP(hipHostMalloc((void**)&e->h_blk_stage, 2 * bytes + 4096));
-        e->h_blk_stage_bytes = 2 * bytes + 4096;
+        KSP_HIP(hipHostMalloc((void**)&e->h_blk_stage, 3 * bytes + 4096));
+        e->h_blk_stage_bytes = 3 * bytes + 4096;
     }
-    KSP_HIP(hipMemcpyAsync(e->h_blk_stage, e->blk_max.p, bytes, hipMemcpyDeviceToHost, st));
-    KSP_HIP(hipMemcpyAsync(e->h_blk_stage + bytes, e->blk_raw.p, bytes, hipMemcpyDeviceToHost, st));
+    // [maxima | sources before every block (padded layouts)], then the list offsets
+    KSP_HIP(hipMemcpyAsync(e->h_blk_stage, e->blk_max.p, e->padded ? 2 * bytes : bytes, hipMemcpyDeviceToHost, st));
+    KSP_HIP(hipMemcpyAsync(e->h_blk_stage + 2 * bytes, e->blk_raw.p, bytes, hipMemcpyDeviceToHost, st));
     e->blk_staged = true;
     return KSP_OK;
 }
@@ -1087,7 +1117,8 @@ static int finish_build(ksp_engine* e) {
         const size_t bytes = ((size_t)e->nb + 1) * 4;
         e->h_blk_off.resize((size_t)e->nb + 1);
         std::memcpy(e->h_blk_max.data(), e->h_blk_stage, bytes);
-        std::memcpy(e->h_blk_off.data(), e->h_blk_stage + bytes, bytes);
+        std::memcpy(e->h_blk_off.data(), e->h_blk_stage + 2 * bytes, bytes);
+        if (e->padded) std::memcpy(e->h_blk_src.data(), e->h_blk_stage + bytes, bytes);
         e->blk_staged = false;
         u32 big_blocks = 0;
         for (u32 b = 0; b < e->nb; ++b) big_blocks += e->h_blk_max[b] >= 65536u;
@@ -1099,6 +1130,8 @@ static int finish_build(ksp_engine* e) {
         return KSP_OK;
     }
     KSP_HIP(hipMemcpy(e->h_blk_max.data(), e->blk_max.p, ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
+    if (e->padded)
+        KSP_HIP(hipMemcpy(e->h_blk_src.data(), e->blk_max.as<u32>() + ((size_t)e->nb + 1), ((size_t)e->nb + 1) * 4, hipMemcpyDeviceToHost));
     {
         u32 big_blocks = 0;
         for (u32 b = 0; b < e->nb; ++b) big_blocks += e->h_blk_max[b] >= 65536u;
@@ -1132,9 +1165,11 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     // sets into enough slices by itself
     if (n >= (1ull << 30) && !(slice && nparts > 1)) { set_error("build: more than 2^30 key entries per call"); return KSP_E_LIMIT; }
     if (n && !d_keys) { set_error("build: d_keys is NULL"); return KSP_E_ARG; }
+    if (const char* ro = std::getenv("KSP_REORDER")) e->reorder = std::atoi(ro) != 0;   // diagnostic / tests
     e->n_sources = n_sources;
     e->n_entries = n;
-    e->nb = (n_sources + TB - 1) / TB;
+    e->nb = blocks_for(n_sources, e->reorder);
+    e->padded = e->nb > (n_sources + TB - 1) / TB;
     e->weighted = d_weights != nullptr;
     e->key_bits = key_bits;
     e->have_max_key = false;
@@ -1160,6 +1195,8 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     e->n_kept = 0;
     e->h_blk_off.assign((size_t)e->nb + 1, 0);
     e->h_blk_max.assign((size_t)e->nb + 1, 0);
+    e->h_blk_src.resize((size_t)e->nb + 1);
+    for (u32 b = 0; b <= e->nb; ++b) e->h_blk_src[b] = (u32)std::min<u64>(n_sources, (u64)b * TB);   // (until a padded build reports its own)
     std::memset(e->slice_hdr, 0, sizeof e->slice_hdr);
     if (n == 0 || e->nb == 0) return KSP_OK;   // nothing can intersect
     int rc;
@@ -1171,7 +1208,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     }
     {   // fine cells: ~32 entries of the largest block per cell, power of two, index kept below 1 GiB
         u64 dmax = 0;
-        for (u32 b = 0; b < e->nb; ++b) {
+        for (u32 b = 0; (u64)b * TB < n_sources; ++b) {
             u64 lo = h_offsets[(u64)b * TB], hi = h_offsets[std::min<u64>(n_sources, (u64)(b + 1) * TB)];
             dmax = std::max(dmax, hi - lo);
         }
@@ -1182,8 +1219,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
         const char* jm = std::getenv("KSP_JOIN");
         e->use_cells = !(jm && std::string(jm) == "window");
     }
-    if ((rc = e->blk_max.ensure(((size_t)e->nb + 2) * 4))) return rc;
-    if (const char* ro = std::getenv("KSP_REORDER")) e->reorder = std::atoi(ro) != 0;   // diagnostic / tests
+    if ((rc = e->blk_max.ensure((2 * (size_t)e->nb + 4) * 4))) return rc;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const int phase = slice ? 1 : 0;   // a slice stops at the source labels (ksp_engine_slice_finish does the rest)
         rc = build_dispatch(e, d_keys, d_weights, st, phase);
@@ -1232,9 +1268,11 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
     for (u32 k = 0; k < n_keys; ++k)
         if (h_key_off[k + 1] < h_key_off[k] + 2) { set_error("build_postings: every key needs at least two holders"); return KSP_E_ARG; }
     if (n >= (1ull << 30)) { set_error("build_postings: more than 2^30 entries per call"); return KSP_E_LIMIT; }
+    if (const char* ro = std::getenv("KSP_REORDER")) e->reorder = std::atoi(ro) != 0;
     e->n_sources = n_sources;
     e->n_entries = n;
-    e->nb = (n_sources + TB - 1) / TB;
+    e->nb = blocks_for(n_sources, e->reorder);
+    e->padded = e->nb > (n_sources + TB - 1) / TB;
     e->weighted = d_key_weights != nullptr;
     e->key_bits = 0;
     e->have_max_key = false;
@@ -1251,6 +1289,8 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
     e->n_kept = 0;
     e->h_blk_off.assign((size_t)e->nb + 1, 0);
     e->h_blk_max.assign((size_t)e->nb + 1, 0);
+    e->h_blk_src.resize((size_t)e->nb + 1);
+    for (u32 b = 0; b <= e->nb; ++b) e->h_blk_src[b] = (u32)std::min<u64>(n_sources, (u64)b * TB);
     e->have_bits = false;
     if (n == 0 || e->nb == 0) {   // nothing can intersect
         e->st.n_block_keys = 0;
@@ -1269,8 +1309,7 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
         const char* jm = std::getenv("KSP_JOIN");
         e->use_cells = !(jm && std::string(jm) == "window");
     }
-    if ((rc = e->blk_max.ensure(((size_t)e->nb + 2) * 4))) return rc;
-    if (const char* ro = std::getenv("KSP_REORDER")) e->reorder = std::atoi(ro) != 0;
+    if ((rc = e->blk_max.ensure((2 * (size_t)e->nb + 4) * 4))) return rc;
     // key offsets as 32-bit device array (= first entry of every rank)
     if ((rc = e->d_off.ensure(((size_t)n_keys + 2) * 4))) return rc;
     {
@@ -1489,7 +1528,7 @@ uint64_t ksp_engine_tile_pairs(const ksp_engine* e, uint64_t t0, uint64_t t1) {
     u64 T = ksp_engine_num_tiles(e);
     if (t1 > T) t1 = T;
     u64 pairs = 0;
-    const u64 last = e->n_sources - (u64)(e->nb - 1) * TB;   // sources in the last block
+    const std::vector<u32>& P = e->h_blk_src;   // sources in the blocks before block b
     u64 t = t0;
     while (t < t1) {
         u32 I, J;
@@ -1497,15 +1536,11 @@ uint64_t ksp_engine_tile_pairs(const ksp_engine* e, uint64_t t0, uint64_t t1) {
         // rest of row I inside [t, t1)
         u64 row_end = tile_row_start((u64)I + 1, e->nb);
         u64 stop = std::min(row_end, t1);
-        u64 nI = (I == e->nb - 1) ? last : TB;
-        // tiles (I, J .. J + cnt - 1) in closed form: the diagonal one, full blocks, the (shorter) last block
+        const u64 nI = P[I + 1] - P[I];
+        // tiles (I, J .. J + cnt - 1) in closed form: the diagonal one, then the sources of the other blocks
         u64 cnt = stop - t, J0 = J;
-        if (J0 == I) { pairs += nI * (nI - 1) / 2; ++J0; --cnt; }
-        if (cnt) {
-            const u64 J1 = J0 + cnt - 1;                     // last column of this piece
-            const u64 full = J1 == e->nb - 1 ? cnt - 1 : cnt;
-            pairs += nI * (full * TB + (J1 == e->nb - 1 ? last : 0));
-        }
+        if (J0 == I) { pairs += nI * (nI ? nI - 1 : 0) / 2; ++J0; --cnt; }
+        if (cnt) pairs += nI * (u64)(P[J0 + cnt] - P[J0]);
         t = stop;
     }
     return pairs;
@@ -1516,12 +1551,12 @@ uint64_t ksp_engine_edge_bound(const ksp_engine* e, uint64_t t0, uint64_t t1) {
     if (!e->sched_on) return ksp_engine_tile_pairs(e, t0, t1);
     const size_t a0 = std::lower_bound(e->act_tid.begin(), e->act_tid.end(), t0) - e->act_tid.begin();
     const size_t a1 = std::lower_bound(e->act_tid.begin(), e->act_tid.end(), t1) - e->act_tid.begin();
-    const u64 last = e->n_sources - (u64)(e->nb - 1) * TB;
+    const std::vector<u32>& P = e->h_blk_src;
     u64 pairs = 0;
     for (size_t i = a0; i < a1; ++i) {
         const u32 I = e->act_rec[4 * i], J = e->act_rec[4 * i + 1];
-        const u64 nI = (I == e->nb - 1) ? last : TB, nJ = (J == e->nb - 1) ? last : TB;
-        pairs += (I == J) ? nI * (nI - 1) / 2 : nI * nJ;
+        const u64 nI = P[I + 1] - P[I], nJ = P[J + 1] - P[J];
+        pairs += (I == J) ? nI * (nI ? nI - 1 : 0) / 2 : nI * nJ;
     }
     return pairs;
 }
@@ -1584,10 +1619,16 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     KSP_HIP(hipEventRecord(e->ev[2], st));
     dim3 block(JW * 64);
     a.blk_max = e->blk_max.as<u32>();
-    a.inv = e->smap.as<u32>() + 3 * (((size_t)e->n_sources + 64) & ~(size_t)63);
+    a.inv = e->smap.as<u32>() + 3 * smap_stride(e);
     a.sched = nullptr; a.act = nullptr; a.wg0 = 0; a.split0 = 0; a.tail_done = nullptr;
     a.collect = e->collect ? 1u : 0u;
     a.mrec = nullptr; a.mstart = nullptr;
+#ifdef KSP_WGTIME
+    static ksp::Buf wgt_buf;   // (timing builds only, tools/wg_times.py)
+    a.wgt = nullptr;
+    const char* wgt_file = std::getenv("KSP_WGTIME_FILE");
+    size_t wgt_n = 0;
+#endif
     auto launch = [&](bool c16, dim3 grid, const JoinArgs& args) {
         if (e->use_cells) {
             if (e->weighted) { if (c16) hipLaunchKernelGGL((k_join<true, true, true>), grid, block, 0, st, args); else hipLaunchKernelGGL((k_join<true, false, true>), grid, block, 0, st, args); }
@@ -1624,6 +1665,14 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
         }
         hipLaunchKernelGGL(k_zero_regions, dim3(256), dim3(256), 0, st, zj);   // (the edge counter and the split tiles' buffers: one launch)
         zj.n = 0;
+#ifdef KSP_WGTIME
+        if (wgt_file) {
+            wgt_n = wgB;
+            if ((rc = wgt_buf.ensure(wgt_n * 128))) return rc;
+            KSP_HIP(hipMemsetAsync(wgt_buf.p, 0, wgt_n * 128, st));
+            a.wgt = wgt_buf.as<unsigned long long>();
+        }
+#endif
         for (int pass = 0; pass < (e->need32 ? 2 : 1); ++pass)
             for (u64 w = wgA; w < wgB; w += kMaxTilesPerLaunch) {
                 a.wg0 = (u32)w;
@@ -1675,6 +1724,13 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     KSP_HIP(hipStreamSynchronize(st));
     KSP_HIP(hipEventElapsedTime(&e->st.ms_join, e->ev[2], e->ev[3]));
     *h_count = *e->h_count;
+#ifdef KSP_WGTIME
+    if (wgt_file && wgt_n) {
+        std::vector<unsigned long long> h(wgt_n * 16);
+        KSP_HIP(hipMemcpy(h.data(), wgt_buf.p, wgt_n * 128, hipMemcpyDeviceToHost));
+        if (FILE* f = std::fopen(wgt_file, "wb")) { std::fwrite(h.data(), 128, wgt_n, f); std::fclose(f); }
+    }
+#endif
     e->st.last_tiles = tile_end - tile_begin;
     e->st.last_active_tiles = e->sched_on ? (u64)(act1 - act0) : tile_end - tile_begin;
     e->st.last_pairs = ksp_engine_tile_pairs(e, tile_begin, tile_end);
@@ -1730,7 +1786,7 @@ int ksp_engine_get_stats(const ksp_engine* e, ksp_stats* out) {
 int ksp_engine_source_order(const ksp_engine* e, uint32_t* h_newidx /* n_sources */) {
     if (!e || !h_newidx) return KSP_E_ARG;
     if (!e->n_sources || !e->smap.p) return KSP_OK;
-    const size_t NN = ((size_t)e->n_sources + 64) & ~(size_t)63;
+    const size_t NN = smap_stride(e);
     KSP_HIP(hipMemcpy(h_newidx, e->smap.as<u32>() + 4 * NN, (size_t)e->n_sources * 4, hipMemcpyDeviceToHost));
     return KSP_OK;
 }
@@ -1986,7 +2042,7 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
             // every device receives every slice: [part][stride] buffers, filled by peer copies from the owners
             u64 lstride = 4, bigstride = 1;
             for (int j = 0; j < nd; ++j) { lstride = std::max(lstride, all_sizes[(size_t)j * 4]); bigstride = std::max(bigstride, all_sizes[(size_t)j * 4 + 2]); }
-            const u32 nb = (N + TB - 1) / TB;
+            const u32 nb = D.e->nb;   // (the same on every device: a function of the source count)
             const bool weighted = job.weights != nullptr;
             const size_t bytes[6] = {lstride * 4, lstride * 4, weighted ? lstride * 4 : 0, ((size_t)nb + 1) * 4, ((size_t)nb + 1) * 4, bigstride * 16};
             for (int q = 0; q < 6 && !rc; ++q) {

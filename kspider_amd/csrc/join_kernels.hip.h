@@ -40,8 +40,18 @@ struct JoinArgs {
     // << 32) per (key, block pair), sorted by tile; tile `i` of the work list owns mrec[mstart[i] .. mstart[i + 1])
     const u64* mrec;
     const u32* mstart;
+#ifdef KSP_WGTIME
+    unsigned long long* wgt;   // (-DKSP_WGTIME builds, tools/wg_times.py) per workgroup: start, end (100 MHz clock), I << 32 | J, sub << 32 | sp
+#endif
 };
 
+#ifdef KSP_WGTIME
+// (timing builds) thread 0 adds the time since its previous mark to slot k of its workgroup's row
+#define WGT_ACC(a, k) do { if ((a).wgt && threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); \
+        unsigned long long* r_ = (a).wgt + 16 * (size_t)((a).wg0 + blockIdx.x); r_[k] += now_ - r_[15]; r_[15] = now_; } } while (0)
+#else
+#define WGT_ACC(a, k) do {} while (0)
+#endif
 __host__ __device__ inline u64 tile_row_start(u64 r, u64 nb) { return r * nb - r * (r - 1) / 2; }
 
 __host__ __device__ inline void tile_decode(u64 t, u32 nb, u32& I, u32& J) {
@@ -598,6 +608,7 @@ __device__ inline void self_tile_popc(const JoinArgs& a, unsigned char* smem, co
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0;
     u32 dacc = 0;
+    WGT_ACC(a, 4);
     for (u32 base = 0; base < klen; base += G * 64) {
         const u32 ng = min(G, (klen - base + 63u) / 64u);
         // transpose 64 masks into 128 column words; a wave takes groups wv, wv + JW, ...  All posting
@@ -630,7 +641,9 @@ __device__ inline void self_tile_popc(const JoinArgs& a, unsigned char* smem, co
                 }
             }
         }
+        WGT_ACC(a, 5);
         __syncthreads();
+        WGT_ACC(a, 6);
         if (off) {
             for (u32 g = 0; g < ng; ++g) {
                 const ulonglong2* r = reinterpret_cast<const ulonglong2*>(col + g * 128u + 4u * ti);
@@ -647,7 +660,9 @@ __device__ inline void self_tile_popc(const JoinArgs& a, unsigned char* smem, co
         if (dia) {
             for (u32 g = 0; g < ng; ++g) dacc += (u32)__popcll(col[g * 128u + s0] & col[g * 128u + s1]);
         }
+        WGT_ACC(a, 7);
         __syncthreads();
+        WGT_ACC(a, 8);
     }
     if (dst) {   // one of several shares: partial counts into the tile's buffer
 #pragma unroll
@@ -656,6 +671,7 @@ __device__ inline void self_tile_popc(const JoinArgs& a, unsigned char* smem, co
             for (int y = 0; y < 4; ++y)
                 if (off && acc[4 * x + y]) atomicAdd(&dst[(4u * ti + (u32)x) * TB + 4u * tj + (u32)y], acc[4 * x + y]);
         if (dia && dacc) atomicAdd(&dst[s0 * TB + s1], dacc);
+        WGT_ACC(a, 9);
         return;
     }
     const u32 g0 = I * TB;
@@ -668,6 +684,7 @@ __device__ inline void self_tile_popc(const JoinArgs& a, unsigned char* smem, co
 #pragma unroll
         for (int y = 0; y < 4; ++y) emit_at(a, g0 + 4u * ti + (u32)x, g0 + 4u * tj + (u32)y, off ? acc[4 * x + y] : 0u, lane, wpos);
     emit_at(a, g0 + s0, g0 + s1, dia ? dacc : 0u, lane, wpos);
+    WGT_ACC(a, 10);
 }
 
 // ---- off-diagonal tile of unweighted blocks: collect the matches, accumulate them bit-sliced ------
@@ -724,6 +741,7 @@ __device__ inline void join_cells_collect(const JoinArgs& a, unsigned char* smem
 #pragma unroll
     for (int i = 0; i < NA; ++i) { acc0[i] = 0; acc1[i] = 0; }
     u32 s0 = 0, s1 = 0, s2 = 0;
+    WGT_ACC(a, 4);
     while (true) {
         __syncthreads();   // (everyone has read the previous round's s_n / s_more)
         if (tid == 0) { s_n = 0; s_more = 0; }
@@ -771,7 +789,9 @@ __device__ inline void join_cells_collect(const JoinArgs& a, unsigned char* smem
             }
             if (have && lane == 0) s_more = 1;
         }
+        WGT_ACC(a, 5);
         __syncthreads();
+        WGT_ACC(a, 6);
         const u32 n = s_n;
         const bool more = s_more != 0;
         for (u32 mb = 0; mb < n; mb += MSUB) {
@@ -793,7 +813,9 @@ __device__ inline void join_cells_collect(const JoinArgs& a, unsigned char* smem
                 __builtin_amdgcn_sched_barrier(0);
                 cl.col[1][wv][64 + lane] = transpose64((u64)mbm.z | ((u64)mbm.w << 32), lane);
             }
+            WGT_ACC(a, 7);
             __syncthreads();
+            WGT_ACC(a, 8);
             const u32 ng = min((u32)(MSUB / 64), (n - mb + 63u) / 64u);
 #pragma unroll 1
             for (u32 g = 0; g < ng; ++g) {
@@ -827,10 +849,13 @@ __device__ inline void join_cells_collect(const JoinArgs& a, unsigned char* smem
                         }
                 }
             }
+            WGT_ACC(a, 9);
             __syncthreads();
+            WGT_ACC(a, 10);
         }
         if (!more) break;
     }
+    WGT_ACC(a, 11);
     // results: partial counts into the tile's buffer (one of several shares) or straight to edges
     const u32 gi = I * TB, gj = J * TB;
     u64 wpos = 0;
@@ -862,6 +887,7 @@ __device__ inline void join_cells_collect(const JoinArgs& a, unsigned char* smem
             }
             __builtin_amdgcn_sched_barrier(0);   // (keeps hipcc from hoisting all 64 id look-ups: registers)
         }
+    WGT_ACC(a, 12);
 }
 
 // ---- off-diagonal tile from its match records (no search) ---------------------------------------
@@ -977,7 +1003,7 @@ __device__ inline void join_matches_collect(const JoinArgs& a, unsigned char* sm
 }
 
 template <bool W, bool C16, bool CELLS>
-__global__ __launch_bounds__(JW * 64, 6) void k_join(JoinArgs a) {   // (6 waves per SIMD = three workgroups per CU: caps the unweighted variant at 80 VGPRs)
+__device__ __forceinline__ void join_workgroup(const JoinArgs& a, u32& I, u32& J, u32& sub, u32& sp) {
     // pair counters (32 KB packed 16-bit / 64 KB 32-bit) + 8 x (1.3 KB B window + 0.5 KB match
     // queue): three (C16) or two workgroups per CU
     constexpr int S_BYTES = (C16 ? TB * TB / 2 : TB * TB) * 4;
@@ -990,8 +1016,8 @@ __global__ __launch_bounds__(JW * 64, 6) void k_join(JoinArgs a) {   // (6 waves
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps index arithmetic and loads scalar
     // Tail splitting: the tiles of the last, partially filled round of workgroup slots are cut
     // into tail_sp rank-range shares each, so that the round takes 1/tail_sp of a tile time.
-    u32 sub = 0, sp = 1, tail_id = 0xFFFFFFFFu;
-    u32 I, J;
+    u32 tail_id = 0xFFFFFFFFu;
+    sub = 0; sp = 1;
     u32 mr0 = 0, mr1 = 0;   // match-list mode: this share's records
     if (a.sched) {
         const u32 wg = a.wg0 + blockIdx.x;
@@ -1095,15 +1121,33 @@ __global__ __launch_bounds__(JW * 64, 6) void k_join(JoinArgs a) {   // (6 waves
         __syncthreads();
         if (tid == 0) s_last = atomicAdd(&a.tail_done[tail_id], 1u) == sp - 1 ? 1u : 0u;
         __syncthreads();
+        WGT_ACC(a, 13);
         if (!s_last) return;
         __threadfence();
         emit_tile(a, I, J, tid, lane, reinterpret_cast<u32*>(wlds),
                   [&](int idx) { return __hip_atomic_load(&dst[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); });
+        WGT_ACC(a, 14);
         return;
     }
     // flush: compact the non-zero counters of the tile into edges (the per-wave LDS is free by now: scratch)
     emit_tile(a, I, J, tid, lane, reinterpret_cast<u32*>(wlds),
               [&](int idx) { return C16 ? ((S[idx >> 1] >> ((idx & 1) * 16)) & 0xFFFFu) : S[idx]; });
+}
+
+template <bool W, bool C16, bool CELLS>
+__global__ __launch_bounds__(JW * 64, 6) void k_join(JoinArgs a) {   // (6 waves per SIMD = three workgroups per CU: caps the unweighted variant at 80 VGPRs)
+    u32 I = 0, J = 0, sub = 0, sp = 1;
+#ifdef KSP_WGTIME
+    const unsigned long long t0 = wall_clock64();
+    if (a.wgt && threadIdx.x == 0) a.wgt[16 * (size_t)(a.wg0 + blockIdx.x) + 15] = t0;
+#endif
+    join_workgroup<W, C16, CELLS>(a, I, J, sub, sp);
+#ifdef KSP_WGTIME
+    if (a.wgt && threadIdx.x == 0) {
+        unsigned long long* r = a.wgt + 16 * (size_t)(a.wg0 + blockIdx.x);
+        r[0] = t0; r[1] = wall_clock64(); r[2] = ((unsigned long long)I << 32) | J; r[3] = ((unsigned long long)sub << 32) | sp;
+    }
+#endif
 }
 
 // one workgroup per tail tile: its summed counters -> edges

@@ -165,6 +165,93 @@ __global__ void k_retag(V* __restrict__ vals, const u32* __restrict__ newidx, u6
         }
     }
 }
+// ---- block boundaries that respect the clusters ------------------------------------------------------------
+// Sources with the same label (a cluster) are contiguous after the (label, id) sort; cutting that order every 128
+// sources lets most clusters straddle a block boundary: their keys then sit in two list words instead of one and the
+// off-diagonal tile of the two blocks is as heavy as a diagonal one (C2: clusters of up to 100 sources, 253 active
+// off-diagonal tiles, the longest workgroups of the join).  So a cluster of at most 128 sources that would cross the
+// end of a block starts the next block instead, and the slots it leaves behind stay empty ("holes": engine indices
+// no source maps to).  The number of blocks is fixed by the host before the labels exist, so the holes have a budget
+// (blocks x 128 - sources); when it is spent the remaining boundaries fall where they fall.  Exactness never depends
+// on where the boundaries are.
+//
+// k_pack_blocks, ONE workgroup: the distance of every sorted position to the head of its cluster goes to LDS (one
+// byte, capped), then one lane walks the chain of block starts (two or three LDS reads per block); bstart[b] = sorted
+// position where block b begins (= sources in the blocks before it), bstart[nb] = n.
+constexpr u32 PACK_MAX = 131072;   // sources (LDS bytes of the distance table)
+__global__ __launch_bounds__(1024) void k_pack_blocks(const u32* __restrict__ labs, const u32 n, const u32 nb,
+                                                      u32* __restrict__ bstart) {
+    __shared__ unsigned char s_d[PACK_MAX];
+    __shared__ u32 s_head[1024];   // last cluster head in or before the thread's chunk, + 1 (0: none yet)
+    __shared__ u32 s_used;
+    const u32 tid = threadIdx.x;
+    const u32 per = (n + 1023u) / 1024u;
+    const u32 p0 = min(n, tid * per), p1 = min(n, p0 + per);
+    u32 last = 0;
+    {
+        u32 prev = p0 ? labs[p0 - 1] : 0u;
+        for (u32 p = p0; p < p1; ++p) {
+            const u32 l = labs[p];
+            if (p == 0 || l != prev) last = p + 1;
+            prev = l;
+        }
+    }
+    s_head[tid] = last;
+    __syncthreads();
+    for (u32 o = 1; o < 1024; o <<= 1) {   // inclusive max-scan (heads ascend with the position)
+        const u32 v = tid >= o ? s_head[tid - o] : 0u;
+        __syncthreads();
+        s_head[tid] = max(s_head[tid], v);
+        __syncthreads();
+    }
+    {
+        u32 head = tid ? s_head[tid - 1] : 0u;   // (+ 1; position 0 is always a head, so 0 never survives the first store)
+        u32 prev = p0 ? labs[p0 - 1] : 0u;
+        for (u32 p = p0; p < p1; ++p) {
+            const u32 l = labs[p];
+            if (p == 0 || l != prev) head = p + 1;
+            prev = l;
+            s_d[p] = (unsigned char)min(p - (head - 1), 255u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const u32 budget = nb * (u32)TB - n;
+        u32 b = 0, k = 0, holes = 0;
+        while (true) {
+            bstart[k] = b;
+            const u32 x = b + (u32)TB;
+            if (x >= n) break;
+            u32 nx = x;
+            const u32 d = s_d[x];
+            if (d != 0 && d < (u32)TB) {            // the cluster at the end of this block began inside it ...
+                const u32 hx = x - d;
+                const bool big = hx + (u32)TB < n && s_d[hx + (u32)TB] >= (u32)TB;   // ... more than 128 members: no block holds it
+                if (!big && holes + d <= budget) { nx = hx; holes += d; }
+            }
+            b = nx;
+            ++k;
+        }
+        s_used = k + 1;   // (<= nb: every block but the last covers 128 slots, sources + holes <= nb x 128)
+    }
+    __syncthreads();
+    for (u32 j = s_used + tid; j <= nb; j += 1024) bstart[j] = n;   // the blocks the holes did not need stay empty
+}
+// slot -> source (inv, ~0 for a hole), source -> slot (newidx) and the largest per-source bound of every block
+__global__ void k_place_sources(const u32* __restrict__ sorted_src, const u32* __restrict__ bstart, u32* __restrict__ newidx,
+                                u32* __restrict__ inv, const u32* __restrict__ src_bound, u32* __restrict__ blk_max, const u32 nb) {
+    const u32 slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nb * (u32)TB) return;
+    const u32 k = slot / (u32)TB, j = slot % (u32)TB;
+    const u32 b0 = bstart[k], b1 = bstart[k + 1];
+    u32 s = ~0u;
+    if (j < b1 - b0) {
+        s = sorted_src[b0 + j];
+        newidx[s] = slot;
+        atomicMax(&blk_max[k], src_bound[s]);
+    }
+    inv[slot] = s;
+}
 // per block (of the new order): the largest per-source bound
 __global__ void k_blk_bound(const u32* __restrict__ src_bound, const u32* __restrict__ newidx, u32* __restrict__ blk_max,
                             u32 n_sources) {

@@ -67,7 +67,7 @@ def build_blocks_sharded(eng, d_keys_ptr: int, h_offsets: np.ndarray, world_size
     else:
         dist.all_gather(list(all_sz.split(4)), mine, group=group)
     sizes = all_sz.cpu().numpy().astype(np.uint64)
-    nb = (len(h_offsets) - 1 + 127) // 128
+    nb = int(eng.stats()["n_blocks"])   # (may exceed ceil(sources / 128): spare blocks for cluster-aligned boundaries)
     lstride = max(4, int(sizes[0::4].max()))
     bigstride = max(1, int(sizes[2::4].max()))
     weighted = d_weights_ptr != 0

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkspider_amd.so")
+LIB_PATH = os.environ.get("KSPIDER_AMD_LIB") or os.path.join(_HERE, "lib", "libkspider_amd.so")   # (override: A/B timing of two builds)
 
 EDGE_DTYPE = np.dtype([("source_1", "<u4"), ("source_2", "<u4"), ("shared", "<u8")])
 
@@ -44,6 +44,7 @@ class Stats(ctypes.Structure):
         ("sort_entries", ctypes.c_uint64), ("ms_sort", ctypes.c_float), ("sort_bits", ctypes.c_int),
         ("partition_kind", ctypes.c_int), ("partition_fallback", ctypes.c_int),
         ("n_match_records", ctypes.c_uint64), ("n_join_workgroups", ctypes.c_uint64),
+        ("n_kept_entries", ctypes.c_uint64), ("n_kept_keys", ctypes.c_uint64),
     ]
 
     def as_dict(self):
@@ -308,6 +309,15 @@ class Engine:
         out = (ctypes.c_uint64 * (nparts + 1))()
         _check(lib().ksp_engine_balanced_cuts(self._h, nparts, out))
         return [int(x) for x in out]
+
+    def source_order(self, n_sources: int) -> np.ndarray:
+        """(diagnostics) engine index (block x 128 + slot) of every source of the last build."""
+        L = lib()
+        L.ksp_engine_source_order.restype = ctypes.c_int
+        L.ksp_engine_source_order.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        out = np.zeros(max(1, n_sources), dtype=np.uint32)
+        _check(L.ksp_engine_source_order(self._h, out.ctypes.data_as(ctypes.c_void_p)))
+        return out[:n_sources]
 
     def edge_bound(self, t0: int, t1: int) -> int:
         """Upper bound on the edges of tiles [t0, t1): source pairs of the tiles that share a key."""

@@ -13,15 +13,17 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["default", "no_reorder", "dense_walk", "collect", "lds_counters", "sort_grouping", "sort_lists",
-                                      "rocprim_partition", "match_join"])
+                                      "rocprim_partition", "match_join", "plain_cuts"])
 def mode(request, monkeypatch):
     """Every case runs seven ways (the last two: keys grouped by the full sort instead of the hash buckets,
     KSP_HASH_GROUP=0; block lists by sorting the entries by block instead of key by key, KSP_KEY_GROUPS=0): as shipped (sources reordered by shared-key label, join over the
     work list of active tiles, accumulation chosen by the postings' sizes), with the caller's source
     order (KSP_REORDER=0), with the reordering but a plain walk over all tiles (KSP_NO_SCHED=1), and with
     the off-diagonal accumulation forced to the bit-sliced collect path / to the LDS counters."""
-    for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_HASH_GROUP", "KSP_KEY_GROUPS", "KSP_PARTITION", "KSP_JOIN"):
+    for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_HASH_GROUP", "KSP_KEY_GROUPS", "KSP_PARTITION", "KSP_JOIN", "KSP_ALIGN"):
         monkeypatch.delenv(k, raising=False)
+    if request.param == "plain_cuts":   # blocks cut every 128 sources of the label order (no spare blocks, no holes)
+        monkeypatch.setenv("KSP_ALIGN", "0")
     if request.param == "match_join":   # off-diagonal tiles from stage 1's match records instead of searching the lists
         monkeypatch.setenv("KSP_JOIN", "matches")
     if request.param == "rocprim_partition":   # the library partition instead of partition_kernels.hip.h
@@ -256,6 +258,59 @@ def test_active_tiles_are_exactly_the_block_pairs_that_share_a_key(oracle_lib, m
         nb = (n + 127) // 128
         if st["n_active_tiles"] != nb * (nb + 1) // 2:      # (mostly-dense inputs walk all tiles)
             assert st["n_active_tiles"] == len(want), (n, st["n_active_tiles"], len(want))
+
+
+def _clustered(rng, sizes, n_core=40, n_own=6):
+    """Sources in shuffled order; cluster c's members share most of its core keys."""
+    member = np.repeat(np.arange(len(sizes)), sizes)
+    rng.shuffle(member)
+    cores = [rng.integers(0, 1 << 58, size=n_core, dtype=np.uint64) for _ in sizes]
+    runs = []
+    for c in member:
+        own = rng.integers(0, 1 << 58, size=n_own, dtype=np.uint64)
+        keep = cores[c][rng.random(n_core) < 0.9] if sizes[c] > 1 else cores[c][:0]
+        runs.append(np.unique(np.concatenate([own, keep])))
+    return synth.from_runs(runs), member
+
+
+def test_block_boundaries_respect_the_clusters(oracle_lib):
+    """k_pack_blocks: a cluster of <= 128 related sources is not cut by a block boundary while the spare slots last
+    (the build holds half as many blocks again as the sources need); bigger clusters and an exhausted budget fall back to
+    plain cuts.  Holes never show: the pair count of all tiles is N (N - 1) / 2 and the edges equal the oracle's."""
+    if os.environ.get("KSP_REORDER") == "0":
+        pytest.skip("boundaries follow the label order")
+    rng = np.random.default_rng(53)
+    aligned = os.environ.get("KSP_ALIGN") != "0"
+    # (a) clusters that fit: 100 + 27 never share a block with a cut in between; (b) 65-source clusters: one per block
+    # costs 63 holes, the budget (half the blocks) runs out; (c) clusters above 128 sources are cut wherever they fall
+    for sizes, fits in (([100] * 12 + [27] * 9 + [1] * 40 + [128, 2, 3], True), ([65] * 40, False), ([300, 129, 90, 200, 50, 17] * 2, None)):
+        sk, member = _clustered(rng, sizes)
+        n = sk.n_sources
+        dk = engine.DeviceBuffer.from_numpy(sk.keys)
+        e = engine.Engine(0)
+        e.build_blocks(dk.ptr.value, sk.offsets)
+        st = e.stats()
+        nb0 = (n + 127) // 128
+        assert st["n_blocks"] == (nb0 + nb0 // 2 + 1 if aligned else nb0)
+        T = e.num_tiles
+        assert T == st["n_blocks"] * (st["n_blocks"] + 1) // 2
+        assert e.tile_pairs(0, T) == n * (n - 1) // 2
+        slot = e.source_order(n)
+        assert len(np.unique(slot)) == n and slot.max() < st["n_blocks"] * 128
+        blocks_of = [np.unique(slot[member == c] // 128) for c in range(len(sizes))]
+        whole = sum(1 for c, b in enumerate(blocks_of) if sizes[c] <= 128 and len(b) == 1)
+        small = sum(1 for c in sizes if c <= 128)
+        if aligned and fits:
+            assert whole == small, (whole, small)
+        if aligned and fits is False:
+            assert small // 2 <= whole < small      # (the budget: 1.5 x 21 + 1 = 32 blocks for 40 clusters of 65)
+        cap = e.edge_bound(0, T) + 1
+        de = engine.DeviceBuffer(cap * 16)
+        cnt = e.join(0, T, de.ptr.value, cap)
+        got = np.sort(de.to_numpy(engine.EDGE_DTYPE, cnt), order=["source_1", "source_2"])
+        ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
+        assert len(got) == len(ref) and (got == ref).all()
+        de.free(); dk.free(); e.close()
 
 
 def test_rank_skew_takes_the_oversized_cell_path(oracle_lib):

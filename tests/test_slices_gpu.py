@@ -12,14 +12,15 @@ pytestmark = pytest.mark.gpu
 def _sliced_edges(sk, nparts, weights=None):
     dk = engine.DeviceBuffer.from_numpy(sk.keys)
     dw = engine.DeviceBuffer.from_numpy(weights) if weights is not None else None
-    nb = (sk.n_sources + 127) // 128
     e = engine.Engine(0)
+    nb = None
     # what the ranks' MIN all-reduce does: element-wise minimum of the slices' source labels
     lab = engine.DeviceBuffer(sk.n_sources * 4)
     labels = np.full(sk.n_sources, 0xFFFFFFFF, dtype=np.uint32)
     for p in range(nparts):
         e.build_slice(dk.ptr.value, sk.offsets, p, nparts, d_weights_ptr=dw.ptr.value if dw else 0)
         e.slice_labels(lab.ptr.value)
+        nb = e.stats()["n_blocks"]   # (blocks of the build: may hold spare ones for cluster-aligned boundaries)
         labels = np.minimum(labels, lab.to_numpy(np.uint32, sk.n_sources))
     lab = engine.DeviceBuffer.from_numpy(labels)
     sizes, parts = [], []

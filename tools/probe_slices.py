@@ -8,9 +8,9 @@ sk = synth.generate("C2", n_sources=N)
 dev = torch.device("cuda", 0)
 keys_d = torch.from_numpy(sk.keys.view(np.int64)).to(dev)
 e = engine.Engine(0)
-nb = (N + 127) // 128
 for it in range(2):
     t = time.time(); e.build_blocks(keys_d.data_ptr(), sk.offsets); torch.cuda.synchronize(); t_full = time.time() - t
+nb = e.stats()["n_blocks"]
 sizes = []; rows = []
 # the ranks' MIN all-reduce of the source labels, emulated on one GPU
 labels = torch.full((N,), 2**31 - 1, dtype=torch.int32, device=dev); lab = torch.empty_like(labels)

@@ -33,6 +33,6 @@ for _ in range(reps):
             order.append(name)
         acc[name] = acc.get(name, 0.0) + ms
 out = {"config": cfg, "env": {k: v for k, v in os.environ.items() if k.startswith("KSP_")}, "build_ms": tb / reps,
-       "join_ms": tj / reps, "edges": cnt, "partition_kind": st["partition_kind"], "partition_fallback": st["partition_fallback"], "matches": st["n_match_records"], "wgs": st["n_join_workgroups"], "active": st["n_active_tiles"],
+       "join_ms": tj / reps, "edges": cnt, "partition_kind": st["partition_kind"], "partition_fallback": st["partition_fallback"], "matches": st["n_match_records"], "wgs": st["n_join_workgroups"], "active": st["n_active_tiles"], "kept": st["n_kept_entries"], "keys": st["n_kept_keys"], "words": st["n_block_keys"],
        "phases": {k: round(acc[k] / reps, 4) for k in order}}
 print(json.dumps(out))

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Per-workgroup timeline of k_join on one config (timing build: `make -C kspider_amd/csrc wgtime`):
+    python tools/wg_times.py [C2]
+Prints the span of the launch, how long the workgroups of each kind (diagonal / off-diagonal, split or not) run,
+when they start, and the longest ones.  Clock: s_memrealtime, 100 MHz (10 ns ticks)."""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("KSPIDER_AMD_LIB", os.path.join(ROOT, "kspider_amd", "lib", "libkspider_amd_wgtime.so"))
+out = os.path.join(tempfile.gettempdir(), "ksp_wgt.bin")
+os.environ["KSP_WGTIME_FILE"] = out
+from kspider_amd import engine, synth  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+sk = synth.generate(cfg)
+dk = engine.DeviceBuffer.from_numpy(sk.keys)
+e = engine.Engine(0)
+e.build_blocks(dk.ptr.value, sk.offsets)
+cap = int(min(e.edge_bound(0, e.num_tiles), 1 << 26)) + 1
+de = engine.DeviceBuffer(cap * 16)
+for _ in range(3):
+    e.join(0, e.num_tiles, de.ptr.value, cap)
+st = e.stats()
+r = np.fromfile(out, dtype=np.uint64).reshape(-1, 16)
+r = r[r[:, 1] != 0]
+t0 = r[:, 0].astype(np.int64)
+t1 = r[:, 1].astype(np.int64)
+I = (r[:, 2] >> np.uint64(32)).astype(np.int64)
+J = (r[:, 2] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+sp = (r[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+base = t0.min()
+us = lambda x: np.asarray(x, dtype=np.float64) / 100.0
+dur = us(t1 - t0)
+print(json.dumps({"config": cfg, "join_ms": st["ms_join"], "workgroups": int(len(r)), "span_us": float(us(t1.max() - base)),
+                  "last_start_us": float(us(t0.max() - base)), "sum_wg_us": float(dur.sum())}))
+for name, sel in (("diag sp=1", (I == J) & (sp == 1)), ("diag split", (I == J) & (sp > 1)), ("off sp=1", (I != J) & (sp == 1)),
+                  ("off split", (I != J) & (sp > 1))):
+    if sel.any():
+        d = dur[sel]
+        print(f"{name:11s} n={sel.sum():6d}  dur us: min {d.min():8.1f} med {np.median(d):8.1f} p90 {np.percentile(d, 90):8.1f} max {d.max():8.1f}"
+              f"  sum {d.sum():10.0f}   start us: med {np.median(us(t0[sel] - base)):7.1f} max {us(t0[sel] - base).max():7.1f}"
+              f"   end us: max {us(t1[sel] - base).max():7.1f}")
+ph = us(r[:, 4:15].astype(np.int64))
+names = {"diag": ["setup", "load+transpose", "barrier", "popcount", "barrier", "partial atomics", "edges (unsplit)", "", "", "fence+done", "last share: edges"],
+         "off": ["setup", "search step", "barrier", "masks+transpose", "barrier", "popcount", "barrier", "loop exit", "edges / partial atomics", "fence+done", "last share: edges"]}
+for kind, sel in (("diag", I == J), ("off", I != J)):
+    if sel.any():
+        print(f"{kind}: mean us per workgroup by phase (thread 0): " + ", ".join(f"{n} {ph[sel, k].mean():.1f}" for k, n in enumerate(names[kind]) if n))
+order = np.argsort(-dur)[:12]
+for i in order:
+    print(f"  wg {i:6d} tile ({I[i]},{J[i]}) sp {sp[i]:3d}: start {us(t0[i] - base):7.1f} dur {dur[i]:7.1f} us  phases " + " ".join(f"{x:.0f}" for x in ph[i]))
