@@ -121,6 +121,11 @@ struct ksp_engine {
     bool part_off = false;        // the hand-written partition gave up on these keys (page tables full): rocPRIM partition
     u32 part_min = 4096;          // entries from which the hand-written partition is used (KSP_PART_MIN)
     ksp::Buf PK, PT, PD, parena;  // level-1 pages of the partition: keys, tags, digit bytes; pools, cursors, page tables
+    bool seg_off = false;         // the segment partition gave up on these keys (a tile or a bucket overflowed): paged levels
+    ksp::Buf seg_tbl, seg_grp;    // segment partition: per source the first entry of every range; first source of every group
+    std::vector<u32> seg_groups;  // host copy of the groups (valid while the offsets and the range count are unchanged)
+    u32 seg_groups_nb1 = 0;
+    bool seg_groups_ok = false;
     ksp::Buf PK2, PT2, PD2;       // pages of the middle level (more than 65 536 buckets)
     ksp::Buf biglist;             // buckets above the LDS table's entry capacity (k_bucket_big)
     // phase timers (ksp_engine_set_profiling): events at the phase starts of the last build / join
@@ -346,6 +351,36 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         if (want <= (256u * 32u * 256u) && !(want > 65536 && std::getenv("KSP_DEBUG_NO_MID"))) nb_hand = (u32)std::max<u64>(1, want);
     }
     const bool hand = nb_hand > 0;
+    // the segment partition (k_seg_bounds / k_seg_scatter): two levels, runs long enough to leave a dozen entries per
+    // (source, range) and no run so long that the one wave that streams it would be the launch
+    bool seg = false;
+    u32 seg_cap = 0, seg_nb1 = 0;
+    int seg_pb2 = 0;
+    if (hand && nb_hand <= 65536 && !e->seg_off && e->h_off.size() == (size_t)N + 1 && N) {
+        const char* sv = std::getenv("KSP_SEG");   // 0: never, 1: whatever the segment length (diagnostic / tests)
+        while (((nb_hand + (1u << seg_pb2) - 1) >> seg_pb2) > 256) ++seg_pb2;
+        seg_nb1 = (nb_hand + (1u << seg_pb2) - 1) >> seg_pb2;
+        const u64 mean_seg = n / N / seg_nb1;
+        seg = (sv ? std::atoi(sv) != 0 : mean_seg >= SEG_MIN_LEN);
+        if (seg) {
+            u64 longest = 0;
+            for (u32 s_ = 0; s_ < N; ++s_) longest = std::max(longest, e->h_off[s_ + 1] - e->h_off[s_]);
+            if (longest > 64 * std::max<u64>(1, n / N) + 65536) seg = false;
+        }
+        if (seg) {
+            const u64 mean = n / nb_hand + 1;
+            seg_cap = (u32)((mean + mean / 2 + 128 + 63) & ~63ull);   // (a multiple of 64 places: every bucket starts on a memory line)
+            if ((u64)nb_hand * seg_cap + P2_TILE >= (1ull << 31)) seg = false;
+        }
+    }
+    const u64 nslots = seg ? (u64)nb_hand * seg_cap + P2_TILE : n;   // places of the partitioned entries (fixed ranges per bucket: with gaps)
+    if (seg) {
+        if ((rc = e->KA.ensure((nslots + 4) * 8))) return rc;
+        if ((rc = e->VB.ensure((nslots + 4) * sizeof(V)))) return rc;
+        if ((rc = e->KB.ensure((nslots / 2 + 1 + 2 * (u64)nb_hand + nb_hand / 2 + 8) * 8))) return rc;
+        KA = e->KA.as<u64>();   // (the buffers may have moved)
+        VB = e->VB.as<V>();
+    }
     e->pre_zeroed_work = e->pre_zeroed_bits = false;
     // layout of the hand-written partition's arena (see the partition step below): level 1 (`A`), and for more than
     // 65 536 buckets a middle level (`M`) between it and the final scatter
@@ -401,7 +436,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         zero_add(z, scal, 128);
         zero_add(z, e->blk_max.p, ((size_t)nb + 1) * 4);
         zero_add(z, e->parena.p, hp_zero_words * 4);
-        zero_add(z, (u64*)e->KB.p + (n / 2 + 1), (size_t)nb_hand * 8);   // bsum (see the partition step)
+        zero_add(z, (u64*)e->KB.p + (nslots / 2 + 1), (size_t)nb_hand * 8);   // bsum (see the partition step)
         if (nb <= KG_WORK) {
             if ((rc = e->dwork.ensure(((size_t)nb + 2) * 8))) return rc;
             zero_add(z, e->dwork.p, ((size_t)nb + 2) * 8);
@@ -514,11 +549,47 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         const u32 nbuckets = hand ? nb_hand : 1u << pb;
         // KB is free until the grouping scans: per-entry records, then the bucket tables
         u32* rec = (u32*)e->KB.p;
-        u64* bsum = (u64*)e->KB.p + (nw / 2 + 1);
+        u64* bsum = (u64*)e->KB.p + ((seg ? nslots : nw) / 2 + 1);
         u64* bbase = bsum + nbuckets;
         u32* bstart = (u32*)(bbase + nbuckets);   // nbuckets + 1
         u32* d_hovf = (u32*)(scal + 9);
-        if (hand) {
+        BucketBounds bb{bstart, nullptr, 0u};
+        if (seg) {
+            // level 1 is already in the sketches (sorted runs): boundaries of every source's segments, then the scatter
+            // gathers its tiles from the segments; fixed places per bucket, the cursors count what arrived
+            const size_t tbl_words = (size_t)N * (seg_nb1 + 1);
+            if ((rc = e->seg_tbl.ensure(tbl_words * 4))) return rc;
+            if (!e->seg_groups_ok || e->seg_groups_nb1 != seg_nb1) {
+                std::vector<u32>& gs = e->seg_groups;
+                gs.clear();
+                gs.push_back(0);
+                const u64 per = (u64)SEG_FILL * seg_nb1;
+                u64 acc = 0;
+                u32 cnt_s = 0;
+                for (u32 s_ = 0; s_ < N; ++s_) {
+                    const u64 len = e->h_off[s_ + 1] - e->h_off[s_];
+                    if (cnt_s && (acc + len > per || cnt_s == SEG_SMAX)) { gs.push_back(s_); acc = 0; cnt_s = 0; }
+                    acc += len;
+                    ++cnt_s;
+                }
+                gs.push_back(N);
+                e->seg_groups_nb1 = seg_nb1;
+                e->seg_groups_ok = true;
+                if ((rc = e->seg_grp.ensure(gs.size() * 4))) return rc;
+                KSP_HIP(hipMemcpyAsync(e->seg_grp.p, gs.data(), gs.size() * 4, hipMemcpyHostToDevice, st));
+            }
+            const u32 ngroups_s = (u32)e->seg_groups.size() - 1;
+            phase_mark(e, st, "partition");
+            KSP_HIP(hipEventRecord(e->ev[4], st));
+            hipLaunchKernelGGL(k_part_src, dim3(1), dim3(64), 0, st, d_off, N, 0u, hp_src, scal, nbuckets);   // (the multiplier of this build)
+            hipLaunchKernelGGL(k_seg_bounds, dim3(N), dim3(64 * SEG_BW), 0, st, d_keys, d_off, N, scal, seg_pb2, nbuckets - 1, seg_nb1,
+                               e->seg_tbl.as<u32>());
+            hipLaunchKernelGGL((k_seg_scatter<V>), dim3(ngroups_s * seg_nb1), dim3(P2_THREADS), 0, st, d_keys, d_off, e->seg_tbl.as<u32>(),
+                               e->seg_grp.as<u32>(), scal, seg_pb2, nbuckets - 1, seg_nb1, seg_cap, hp_gcnt, KA, VB);
+            KSP_HIP(hipEventRecord(e->ev[5], st));
+            phase_mark(e, st, "bucket grouping");
+            bb = BucketBounds{nullptr, hp_gcnt, seg_cap};
+        } else if (hand) {
             // partition by bucket = floor(key * nbuckets / (max key + 1)): d_keys -> level-1 pages [-> middle pages] -> KA, VB, bstart
             if ((rc = e->PK.ensure(hp_pages_a * P1_PAGE * 8))) return rc;
             if ((rc = e->PT.ensure(hp_pages_a * P1_PAGE * sizeof(V)))) return rc;
@@ -565,7 +636,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         }
         e->sort_entries = nw;
         e->sort_bits = pb;
-        e->part_kind = hand ? 2 : 1;
+        e->part_kind = seg ? 3 : hand ? 2 : 1;
         if (!e->hb_slots) {   // persistent workgroups: as many as fit on the device at once
             int per_cu = 0, cus = 0;
             KSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bucket_group, HB_THREADS, 0));
@@ -576,21 +647,26 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         // holders each (C3: a third of the buckets at a mean of 2 000) stays on this path instead of falling back to the sort
         if ((rc = e->biglist.ensure(((size_t)nbuckets + 1) * 4))) return rc;
         u32* big_list = e->biglist.as<u32>();
-        hipLaunchKernelGGL(k_bucket_group, dim3(std::min(nbuckets, e->hb_slots)), dim3(HB_THREADS), 0, st, KA, bstart,
+        hipLaunchKernelGGL(k_bucket_group, dim3(std::min(nbuckets, e->hb_slots)), dim3(HB_THREADS), 0, st, KA, bb,
                            nbuckets, (u32)nw, rec, bsum, d_hovf, big_list);
-        hipLaunchKernelGGL((k_bucket_big<V, 0>), dim3(1024), dim3(HB_THREADS), 0, st, KA, VB, bstart, big_list, d_hovf,
+        hipLaunchKernelGGL((k_bucket_big<V, 0>), dim3(1024), dim3(HB_THREADS), 0, st, KA, VB, bb, big_list, d_hovf,
                            bsum, (const u64*)nullptr, VA, rank1, first);
         size_t tb2 = 0;
         KSP_HIP(rocprim::exclusive_scan(nullptr, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
         if ((rc = e->tmp.ensure(tb2))) return rc;
         KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
-        hipLaunchKernelGGL((k_bucket_emit<V>), dim3((nbuckets + HB_EMIT - 1) / HB_EMIT), dim3(HB_THREADS), 0, st, rec, VB, bstart,
+        hipLaunchKernelGGL((k_bucket_emit<V>), dim3((nbuckets + HB_EMIT - 1) / HB_EMIT), dim3(HB_THREADS), 0, st, rec, VB, bb,
                            bbase, bsum, nbuckets, VA, rank1, first, scal);
-        hipLaunchKernelGGL((k_bucket_big<V, 1>), dim3(1024), dim3(HB_THREADS), 0, st, KA, VB, bstart, big_list, d_hovf,
+        hipLaunchKernelGGL((k_bucket_big<V, 1>), dim3(1024), dim3(HB_THREADS), 0, st, KA, VB, bb, big_list, d_hovf,
                            bsum, bbase, VA, rank1, first);
         KSP_HIP(hipMemcpyAsync(e->h_scal, scal, 120, hipMemcpyDeviceToHost, st));   // [0] max key, [2] keys, [6] entries, [9] / [14] overflow (one copy)
         KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
         if (hand) {
+            if (seg && (u32)e->h_scal[PC_OVF]) {   // a tile or a bucket of the segment partition overflowed: the paged levels from now on
+                e->seg_off = true;
+                e->part_fail = (int)(u32)e->h_scal[PC_OVF];
+                return build_impl<V>(e, d_keys, d_w, st, phase);
+            }
             if ((u32)e->h_scal[PC_OVF]) {   // the page tables could not hold these keys: the library partition from now on
                 e->part_off = true;
                 e->part_fail = (int)(u32)e->h_scal[PC_OVF];
@@ -956,7 +1032,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
-                        &e->d_wg, &e->gp, &e->gm, &e->PK, &e->PT, &e->PD, &e->parena, &e->PK2, &e->PT2, &e->PD2, &e->biglist, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
+                        &e->d_wg, &e->gp, &e->gm, &e->PK, &e->PT, &e->PD, &e->parena, &e->PK2, &e->PT2, &e->PD2, &e->seg_tbl, &e->seg_grp, &e->biglist, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
                         &e->mr0, &e->mr1, &e->mstart};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
@@ -1177,7 +1253,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     e->part_id = part;
     const bool same_offsets = e->d_off_sketch && e->h_off.size() == (size_t)n_sources + 1 &&
                               std::memcmp(e->h_off.data(), h_offsets, ((size_t)n_sources + 1) * 8) == 0;
-    if (!same_offsets) { e->h_off.assign(h_offsets, h_offsets + n_sources + 1); e->d_off_sketch = false; }
+    if (!same_offsets) { e->h_off.assign(h_offsets, h_offsets + n_sources + 1); e->d_off_sketch = false; e->seg_groups_ok = false; }
     e->blk_staged = false;
     if (std::getenv("KSP_FULL_SORT")) e->full_sort = true;   // diagnostic: sort on all key bits
     if (const char* hg = std::getenv("KSP_HASH_GROUP")) e->hash_off = std::atoi(hg) == 0;   // diagnostic / tests

@@ -476,3 +476,184 @@ __global__ __launch_bounds__(P2_THREADS) void k_part_mid(const u64* __restrict__
         }
     }
 }
+
+// ---- level 1 without a copy: the segments of the sorted runs (round 2) ------------------------------------------
+// Every source's run is sorted and the bucket id is monotone in the key, so the entries of one source that belong to
+// one level-1 bucket ("range": 2^pb2 consecutive final buckets) ARE a contiguous segment of its run — the sketch array
+// already is partitioned at level 1, source by source.  Instead of copying the entries into level-1 pages (k_part1:
+// 8 bytes read + 11 written per entry, then 11 read again), only the segment boundaries are written down
+// (k_seg_bounds: one streaming read of the keys, (ranges + 1) words per source), and the final scatter gathers its
+// tile straight from the sketches: workgroup (group of consecutive sources g, range B) reads the B-segments of its
+// sources — ~4 096 entries — and from there on is k_scatter2 (LDS counting sort by final bucket, one reservation per
+// bucket present, runs written out).  There is no histogram pass either: every final bucket owns a fixed number of
+// places (half as many again as the mean) and its cursor counts what arrived; a bucket or a tile that does not fit
+// raises the overflow word and the build is repeated with the paged partition above (the engine remembers).
+// Bytes per entry (8-byte key, 2-byte tag): 8 read + ~10 read (segments of ~200 bytes end in partial lines) + 10
+// written = 28, against 40.  For runs long enough to leave segments of a dozen entries or more (sourmash-style
+// sketches: C2, 5 000 hashes in 196 ranges); everything else keeps the paged levels.
+constexpr u32 SEG_SMAX = 512;     // sources per group (LDS: start slot and address of every segment)
+constexpr u32 SEG_FILL = 3072;    // mean entries of a tile; the tile holds P2_TILE (uniform hashes: +18 sigma)
+constexpr u32 SEG_MIN_LEN = 12;   // mean segment length from which the path is used
+
+// one workgroup per source, a quarter of the run per wave, streamed once: where the range id steps up, the lane at the
+// step writes the boundaries it crosses (bnd[s][j] = first entry of range j or a later one; bnd[s][0] = 0,
+// bnd[s][nb1] = length).  The next windows are requested before the current ones are looked at.
+constexpr u32 SEG_BW = 4;   // waves per source
+__global__ __launch_bounds__(64 * SEG_BW) void k_seg_bounds(const u64* __restrict__ keys, const u64* __restrict__ off, const u32 n_sources,
+                                                            u64* __restrict__ scal, const int pb2, const u32 nbm1, const u32 nb1,
+                                                            u32* __restrict__ bnd) {
+    const u32 s = blockIdx.x, part = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (s >= n_sources) return;
+    const u64 mult = scal[PC_MULT];
+    const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
+    const u64 b = off[s];
+    const u32 len = (u32)(off[s + 1] - b);
+    const u32 a0 = (u32)(((u64)len * part) / SEG_BW), a1 = (u32)(((u64)len * (part + 1)) / SEG_BW);
+    const bool last = part == SEG_BW - 1;
+    u32* const row = bnd + (size_t)s * (nb1 + 1);
+    if (part == 0 && lane == 0) row[0] = 0;
+    u32 carry = a0 ? (part_bucket(keys[b + a0 - 1], mult, ident, nbm1) >> pb2) : 0u;   // range of the entry in front of this part
+    constexpr u32 UN = 4;
+    u64 k[UN], kn[UN];
+#pragma unroll
+    for (u32 q = 0; q < UN; ++q) {
+        const u32 i = a0 + q * 64 + lane;
+        k[q] = i < a1 ? __builtin_nontemporal_load(keys + b + i) : 0;
+    }
+    for (u32 i0 = a0; i0 < a1; i0 += 64 * UN) {
+#pragma unroll
+        for (u32 q = 0; q < UN; ++q) {
+            const u32 i = i0 + (UN + q) * 64 + lane;
+            kn[q] = i < a1 ? __builtin_nontemporal_load(keys + b + i) : 0;
+        }
+#pragma unroll
+        for (u32 q = 0; q < UN; ++q) {
+            const u32 i = i0 + q * 64 + lane;
+            if (i0 + q * 64 >= a1) break;   // (uniform)
+            // the last part: entries behind the end count as range nb1 — the first of them closes every boundary still open
+            const u32 r = i < a1 ? (part_bucket(k[q], mult, ident, nbm1) >> pb2) : (last ? nb1 : 0u);
+            u32 pr = __shfl_up(r, 1);
+            if (lane == 0) pr = carry;
+            if (r > pr && (i < a1 || (last && i == a1)))
+                for (u32 j = pr + 1; j <= r; ++j) row[j] = i;
+            carry = __shfl(r, 63);
+        }
+#pragma unroll
+        for (u32 q = 0; q < UN; ++q) k[q] = kn[q];
+    }
+    if (last && lane == 0)   // (a run that ends with a full window, or an empty one)
+        for (u32 j = carry + 1; j <= nb1; ++j) row[j] = len;
+}
+
+// one workgroup per (group of sources, range): gather the tile from the segments, then the counting sort of k_scatter2.
+// gcur[b] (zero at launch) counts the entries of final bucket b, which owns the places [b x cap, (b + 1) x cap).
+template <class V>
+__global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restrict__ keys, const u64* __restrict__ off,
+                                                            const u32* __restrict__ bnd, const u32* __restrict__ groups,
+                                                            u64* __restrict__ scal, const int pb2, const u32 nbm1, const u32 nb1,
+                                                            const u32 cap, u32* __restrict__ gcur,
+                                                            u64* __restrict__ K2, V* __restrict__ T2) {
+    __shared__ u64 s_key[P2_TILE];
+    __shared__ V s_tag[P2_TILE];
+    __shared__ u8 s_bin[P2_TILE];
+    __shared__ u32 s_ls[256], s_cnt[256], s_gb[256];
+    __shared__ u32 s_pre[SEG_SMAX + 1], s_addr[SEG_SMAX];
+    __shared__ u32 s_w[P2_THREADS / 64];
+    u32* const ovf = reinterpret_cast<u32*>(scal + PC_OVF);
+    if (*ovf) return;
+    const u32 g = blockIdx.x / nb1, B = blockIdx.x % nb1;   // (consecutive workgroups read neighbouring segments of the same sources)
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 s0 = groups[g], ns = groups[g + 1] - s0;        // (<= SEG_SMAX by construction)
+    // the segments: start address and length, exclusive scan of the lengths = start slot inside the tile
+    u32 len = 0;
+    if (tid < ns) {
+        const u32* row = bnd + (size_t)(s0 + tid) * (nb1 + 1) + B;
+        const u32 lo = row[0], hi = row[1];
+        len = hi - lo;
+        s_addr[tid] = (u32)off[s0 + tid] + lo;   // (fewer than 2^30 entries per build)
+    }
+    u32 inc = len;
+    for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+    if (lane == 63) s_w[wv] = inc;
+    if (tid < 256) s_cnt[tid] = 0;
+    __syncthreads();
+    u32 run = inc - len, m = 0;
+    for (u32 w = 0; w < P2_THREADS / 64; ++w) { if (w < wv) run += s_w[w]; m += s_w[w]; }
+    if (tid < ns) s_pre[tid] = run;
+    if (tid == 0) s_pre[ns] = m;
+    if (m > P2_TILE) {   // (keys far from uniform: the paged partition takes this build)
+        if (tid == 0) __hip_atomic_store(ovf, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    __syncthreads();
+    // gather straight into registers: entry i of the tile lies in the segment sg with s_pre[sg] <= i < s_pre[sg + 1]
+    // (bisection in LDS; neighbouring threads read neighbouring entries of the same segment).  All loads of a thread
+    // are in flight together: a loop over the segments would be one memory round trip per segment.
+    const u32 nb2m1 = (1u << pb2) - 1u;
+    const u64 mult = scal[PC_MULT];
+    const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
+    u64 key[P2_EPT];
+    V tag[P2_EPT];
+    u32 rk[P2_EPT];
+#pragma unroll
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        key[k] = 0; tag[k] = V(0);
+        if (i < m) {
+            u32 lo = 0, hi = ns;   // s_pre[lo] <= i < s_pre[hi]
+            while (hi - lo > 1) {
+                const u32 mid = (lo + hi) >> 1;
+                if (s_pre[mid] <= i) lo = mid; else hi = mid;
+            }
+            key[k] = __builtin_nontemporal_load(keys + s_addr[lo] + (i - s_pre[lo]));
+            const u32 src = s0 + lo;
+            tag[k] = make_tag<V>(((src / TB) << 8) | (src % TB), 0u);
+        }
+    }
+#pragma unroll
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        rk[k] = part_bucket(key[k], mult, ident, nbm1) & nb2m1;
+        if (i < m) rk[k] |= atomicAdd(&s_cnt[rk[k]], 1u) << 8;
+    }
+    __syncthreads();   // (also: every thread holds its entries in registers, the staging buffers are free)
+    if (wv == 0) {   // where every bucket's run starts inside the tile
+        u32 c[4], t = 0;
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) { c[i] = s_cnt[4 * lane + i]; t += c[i]; }
+        u32 in2 = t;
+        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(in2, o); if ((int)lane >= o) in2 += up; }
+        u32 r2 = in2 - t;
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) { s_ls[4 * lane + i] = r2; r2 += c[i]; }
+    } else if (tid - 64 < 256) {   // ... and among the bucket's places: one atomic per bucket present in the tile
+        const u32 bin = tid - 64, c = s_cnt[bin];
+        if (c) {
+            const u32 bkt = (B << pb2) + bin;
+            const u32 at = atomicAdd(&gcur[bkt], c);
+            if (at + c > cap) __hip_atomic_store(ovf, 5u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the stores below stay inside the arrays: see the host side)
+            s_gb[bin] = bkt * cap + min(at, cap);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        if (i < m) {
+            const u32 bin = rk[k] & 0xFFu, slot = s_ls[bin] + (rk[k] >> 8);
+            s_key[slot] = key[k];
+            s_tag[slot] = tag[k];
+            s_bin[slot] = (u8)bin;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        if (i < m) {
+            const u32 bin = s_bin[i], dst = s_gb[bin] + (i - s_ls[bin]);
+            K2[dst] = s_key[i];
+            T2[dst] = s_tag[i];
+        }
+    }
+}

@@ -185,17 +185,14 @@ __global__ __launch_bounds__(1024) void k_pack_blocks(const u32* __restrict__ la
     __shared__ u32 s_head[1024];   // last cluster head in or before the thread's chunk, + 1 (0: none yet)
     __shared__ u32 s_used;
     const u32 tid = threadIdx.x;
+    // head flags, read in full lines (a thread's chunk below is contiguous: it would read the labels one word per line)
+    for (u32 p = tid; p < n; p += 1024) s_d[p] = (p == 0 || labs[p] != labs[p - 1]) ? 1 : 0;
+    __syncthreads();
     const u32 per = (n + 1023u) / 1024u;
     const u32 p0 = min(n, tid * per), p1 = min(n, p0 + per);
     u32 last = 0;
-    {
-        u32 prev = p0 ? labs[p0 - 1] : 0u;
-        for (u32 p = p0; p < p1; ++p) {
-            const u32 l = labs[p];
-            if (p == 0 || l != prev) last = p + 1;
-            prev = l;
-        }
-    }
+    for (u32 p = p0; p < p1; ++p)
+        if (s_d[p]) last = p + 1;
     s_head[tid] = last;
     __syncthreads();
     for (u32 o = 1; o < 1024; o <<= 1) {   // inclusive max-scan (heads ascend with the position)
@@ -206,11 +203,8 @@ __global__ __launch_bounds__(1024) void k_pack_blocks(const u32* __restrict__ la
     }
     {
         u32 head = tid ? s_head[tid - 1] : 0u;   // (+ 1; position 0 is always a head, so 0 never survives the first store)
-        u32 prev = p0 ? labs[p0 - 1] : 0u;
         for (u32 p = p0; p < p1; ++p) {
-            const u32 l = labs[p];
-            if (p == 0 || l != prev) head = p + 1;
-            prev = l;
+            if (s_d[p]) head = p + 1;
             s_d[p] = (unsigned char)min(p - (head - 1), 255u);
         }
     }
@@ -244,13 +238,16 @@ __global__ void k_place_sources(const u32* __restrict__ sorted_src, const u32* _
     if (slot >= nb * (u32)TB) return;
     const u32 k = slot / (u32)TB, j = slot % (u32)TB;
     const u32 b0 = bstart[k], b1 = bstart[k + 1];
-    u32 s = ~0u;
+    u32 s = ~0u, bound = 0;
     if (j < b1 - b0) {
         s = sorted_src[b0 + j];
         newidx[s] = slot;
-        atomicMax(&blk_max[k], src_bound[s]);
+        bound = src_bound[s];
     }
     inv[slot] = s;
+    // (a wave's 64 slots lie in one block: one atomic per wave — 128 on the same word are served one at a time)
+    for (int o = 32; o > 0; o >>= 1) bound = max(bound, (u32)__shfl_xor(bound, o));
+    if ((threadIdx.x & 63) == 0 && bound) atomicMax(&blk_max[k], bound);
 }
 // per block (of the new order): the largest per-source bound
 __global__ void k_blk_bound(const u32* __restrict__ src_bound, const u32* __restrict__ newidx, u32* __restrict__ blk_max,
@@ -416,6 +413,16 @@ constexpr u32 HB_KEPT = 1u << 31, HB_FIRST = 1u << 30;   // per-entry record: ke
 constexpr u32 HB_EMIT = 8;       // buckets per workgroup of the emit kernel
 constexpr u32 HB_BIG_DISTINCT = 3072;   // k_bucket_big: distinct keys per oversize bucket (any number of such buckets: the list holds one slot per bucket)
 
+// Where a bucket's entries sit: dense (bucket b = [start[b], start[b + 1]), the paged / library partitions) or one
+// fixed range of `cap` places per bucket of which cnt[b] are used (the segment partition, k_seg_scatter).
+struct BucketBounds {
+    const u32* start;
+    const u32* cnt;
+    u32 cap;
+    __device__ u32 first(const u32 b) const { return cap ? b * cap : start[b]; }
+    __device__ u32 size(const u32 b) const { return cap ? min(cnt[b], cap) : start[b + 1] - start[b]; }
+};
+
 __global__ void k_bucket_bounds(const u64* __restrict__ keys, u64 n, int shiftb, u32 nbuckets, u32* __restrict__ bstart) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nbuckets) return;
@@ -431,7 +438,7 @@ __global__ void k_bucket_bounds(const u64* __restrict__ keys, u64 n, int shiftb,
 // Persistent workgroups, buckets b = blockIdx.x, += gridDim.x: while a bucket is grouped, the bounds
 // and then the keys of the workgroup's next bucket are already on their way (the kernel is a chain
 // of memory round trips otherwise).  bsum[] is zero at launch (trailing empty buckets are not visited).
-__global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __restrict__ keys, const u32* __restrict__ bstart,
+__global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __restrict__ keys, const BucketBounds bb,
                                                              u32 nbuckets, u32 nw, u32* __restrict__ rec,
                                                              u64* __restrict__ bsum, u32* __restrict__ overflow,
                                                              u32* __restrict__ big_list) {
@@ -450,20 +457,20 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
     const u32 tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     u32 b = blockIdx.x;
-    u32 b0 = nw, raw = 0;
-    if (b < nbuckets) { b0 = bstart[b]; raw = bstart[b + 1] - b0; }
+    u32 b0 = 0, raw = 0;
+    if (b < nbuckets) { b0 = bb.first(b); raw = bb.size(b); }
     u32 size = raw > HB_CAP ? 0 : raw;   // a bucket that does not fit is skipped here: k_bucket_big takes it
     unsigned long long mykey[EPT], nkey[EPT];
 #pragma unroll
     for (u32 j = 0; j < EPT; ++j) mykey[j] = tid + j * NT < size ? keys[b0 + tid + j * NT] : 0;
-    while (b < nbuckets && b0 < nw) {   // (b0 == nw: this bucket and every later one is empty)
+    while (b < nbuckets) {
         if (raw > HB_CAP && tid == 0) {   // left to k_bucket_big (overflow[1] counts them)
             const u32 q = atomicAdd(&overflow[1], 1u);
             big_list[q] = b;   // (one slot per bucket: cannot overflow)
         }
         const u32 bn = b + gridDim.x;
-        u32 n0 = nw, nraw = 0;          // bounds of the next bucket
-        if (bn < nbuckets) { n0 = bstart[bn]; nraw = bstart[bn + 1] - n0; }
+        u32 n0 = 0, nraw = 0;           // bounds of the next bucket
+        if (bn < nbuckets) { n0 = bb.first(bn); nraw = bb.size(bn); }
         // the table is as large as the bucket needs (load at most 13/16 even if no two keys are equal)
         const u32 slots = size <= 416 ? 512u : size <= 832 ? 1024u : size <= 1664 ? 2048u : HB_SLOTS;
         for (u32 i = tid; i <= slots; i += NT) tkey[i] = EMPTY;
@@ -547,7 +554,7 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
 // such a bucket (thousands of keys under one prefix) is the one case left for the sort path (*overflow).
 template <class V, int PART>
 __global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict__ keys, const V* __restrict__ vals,
-                                                           const u32* __restrict__ bstart, const u32* __restrict__ big_list,
+                                                           const BucketBounds bb, const u32* __restrict__ big_list,
                                                            u32* __restrict__ overflow, u64* __restrict__ bsum,
                                                            const u64* __restrict__ bbase, V* __restrict__ vals2,
                                                            u32* __restrict__ rank2, u32* __restrict__ first) {
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (u32 q = blockIdx.x; q < n_big; q += gridDim.x) {   // (a few workgroups walk the list: it is empty for most inputs)
     const u32 b = big_list[q];
-    const u32 b0 = bstart[b], size = bstart[b + 1] - b0;
+    const u32 b0 = bb.first(b), size = bb.size(b);
     __syncthreads();   // (the table of the previous bucket is no longer read)
     for (u32 i = tid; i <= HB_SLOTS; i += NT) { tkey[i] = EMPTY; tcnt[i] = 0; tfill[i] = 0; }
     if (tid == 0) s_distinct = 0;
@@ -633,26 +640,27 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict
 // order in LDS and leaves in full lines.  One workgroup handles HB_EMIT consecutive buckets.
 template <class V>
 __global__ __launch_bounds__(HB_THREADS) void k_bucket_emit(const u32* __restrict__ rec, const V* __restrict__ vals,
-                                                            const u32* __restrict__ bstart, const u64* __restrict__ bbase,
+                                                            const BucketBounds bb, const u64* __restrict__ bbase,
                                                             const u64* __restrict__ bsum, u32 nbuckets,
                                                             V* __restrict__ vals2, u32* __restrict__ rank2,
                                                             u32* __restrict__ first, u64* __restrict__ scal) {
     constexpr u32 NT = HB_THREADS, EPT = HB_CAP / NT;
-    __shared__ u32 s_start[HB_EMIT + 1];
+    __shared__ u32 s_start[HB_EMIT], s_size[HB_EMIT];
     __shared__ u64 s_base[HB_EMIT], s_sum[HB_EMIT];
     __shared__ V o_tag[HB_CAP];
     __shared__ unsigned short o_rank[HB_CAP], o_first[HB_CAP / 2];
     const u32 tid = threadIdx.x;
     const u32 g0 = blockIdx.x * HB_EMIT;
-    if (tid <= HB_EMIT) s_start[tid] = bstart[min(g0 + tid, nbuckets)];
     if (tid < HB_EMIT) {
         const bool in = g0 + tid < nbuckets;
+        s_start[tid] = in ? bb.first(g0 + tid) : 0;
+        s_size[tid] = in ? bb.size(g0 + tid) : 0;
         s_base[tid] = in ? bbase[g0 + tid] : 0;
         s_sum[tid] = in ? bsum[g0 + tid] : 0;
     }
     __syncthreads();
     for (u32 q = 0; q < HB_EMIT; ++q) {
-        const u32 b0 = s_start[q], size = s_start[q + 1] - b0;
+        const u32 b0 = s_start[q], size = s_size[q];
         const u64 sum = s_sum[q];
         if (sum == 0 || size > HB_CAP) continue;   // nothing kept (or a bucket the group kernel skipped)
         u32 r[EPT];

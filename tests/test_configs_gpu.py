@@ -120,7 +120,7 @@ def test_c2_full_size_edge_set_equals_restated_reference(oracle_lib):
     e = engine.Engine(0)
     e.build_blocks(dk.ptr.value, sk.offsets)
     st = e.stats()
-    assert st["partition_kind"] == 2 and st["partition_fallback"] == 0, st   # the hand-written partition, no fallback
+    assert st["partition_kind"] == 3 and st["partition_fallback"] == 0, st   # the segment partition (level 1 read off the sorted runs), no fallback
     ev, _ = _join_all(e, int(e.edge_bound(0, e.num_tiles)) + 1)
     assert len(ev) == n_edges == len(ref)
     assert (ev["source_1"] + 1 == ref["source_1"]).all() and (ev["source_2"] + 1 == ref["source_2"]).all()

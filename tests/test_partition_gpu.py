@@ -12,20 +12,27 @@ pytestmark = pytest.mark.gpu
 
 
 def _edges(sk, monkeypatch, **env):
-    for k in ("KSP_PARTITION", "KSP_PART_MIN", "KSP_DEBUG_BUCKET_MEAN"):
+    for k in ("KSP_PARTITION", "KSP_PART_MIN", "KSP_DEBUG_BUCKET_MEAN", "KSP_SEG"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     return engine.pairwise_host(sk.keys, sk.offsets)
 
 
-def _both(sk, monkeypatch, oracle=None, expect_hand=True):
-    hand, st = _edges(sk, monkeypatch, KSP_PART_MIN="1")
+def _both(sk, monkeypatch, oracle=None, expect_hand=True, expect_seg=None):
+    """Paged partition (KSP_SEG=0), segment partition forced (KSP_SEG=1: level 1 read off the sorted runs; a tile or
+    bucket that does not fit sends the build back to the paged one, partition_fallback 4 / 5) and the library's."""
+    hand, st = _edges(sk, monkeypatch, KSP_PART_MIN="1", KSP_SEG="0")
+    seg, st_seg = _edges(sk, monkeypatch, KSP_PART_MIN="1", KSP_SEG="1")
     lib, st_lib = _edges(sk, monkeypatch, KSP_PARTITION="rocprim")
     assert st_lib["partition_kind"] in (0, 1)
     assert st["partition_fallback"] in (0, 1), st      # (2 / 3 would be defects of the partition itself)
     if expect_hand:
         assert st["partition_kind"] == 2 and st["partition_fallback"] == 0, st
+    assert st_seg["partition_fallback"] in (0, 1, 4, 5), st_seg
+    if expect_seg is not None:
+        assert (st_seg["partition_kind"] == 3 and st_seg["partition_fallback"] == 0) == expect_seg, st_seg
+    assert len(seg) == len(lib) and (seg == lib).all()
     assert len(hand) == len(lib) and (hand == lib).all()
     if oracle is not None:
         ref = oracle.brute_pairs(sk.keys, sk.offsets)
@@ -58,7 +65,7 @@ def test_pages_chunks_and_ragged_sources(oracle_lib, monkeypatch):
 @pytest.mark.parametrize("n_sources,size", [(3, 5), (40, 100), (513, 700), (2000, 2100)])
 def test_small_and_medium_sets(oracle_lib, monkeypatch, n_sources, size):
     sk = synth.generate("C2", n_sources=n_sources, mean_size=size, cluster_cap=max(2, n_sources // 20), seed=900 + n_sources)
-    _both(sk, monkeypatch, oracle_lib)
+    _both(sk, monkeypatch, oracle_lib, expect_seg=True)
 
 
 def test_full_width_keys_and_the_largest_key(oracle_lib, monkeypatch):
@@ -89,14 +96,17 @@ def test_skewed_keys_overflow_the_page_tables_and_fall_back(oracle_lib, monkeypa
         high = rng.integers(0, 1 << 57, size=20, dtype=np.uint64)
         runs.append(np.unique(np.concatenate([low, high, np.arange(s % 5, 4000, 5, dtype=np.uint64)])))
     sk = synth.from_runs(runs)
-    hand, st = _edges(sk, monkeypatch, KSP_PART_MIN="1")
+    hand, st = _edges(sk, monkeypatch, KSP_PART_MIN="1")                             # (segment partition first: a tile overflows)
     assert st["partition_kind"] == 1 and st["partition_fallback"] == 1, st          # fell back: page tables full
     ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
     assert len(hand) == len(ref) and (hand == ref).all()
 
 
-def test_rebuilds_on_one_engine_give_the_same_edges(monkeypatch):
-    """The page pools, cursors and page tables are reset per build: ten builds on one engine, same edge set."""
+@pytest.mark.parametrize("seg", ["0", "1"])
+def test_rebuilds_on_one_engine_give_the_same_edges(monkeypatch, seg):
+    """The page pools, cursors and page tables (the bucket cursors of the segment partition) are reset per build: ten
+    builds on one engine, same edge set."""
+    monkeypatch.setenv("KSP_SEG", seg)
     sk = synth.generate("C2", n_sources=1500, mean_size=1500, cluster_cap=60, seed=321)
     dk = engine.DeviceBuffer.from_numpy(sk.keys)
     e = engine.Engine(0)
@@ -105,7 +115,7 @@ def test_rebuilds_on_one_engine_give_the_same_edges(monkeypatch):
     first = None
     for _ in range(10):
         e.build_blocks(dk.ptr.value, sk.offsets)
-        assert e.stats()["partition_kind"] == 2
+        assert e.stats()["partition_kind"] == (3 if seg == "1" else 2)
         cnt = e.join(0, e.num_tiles, de.ptr.value, cap)
         ev = np.sort(de.to_numpy(engine.EDGE_DTYPE, cnt), order=["source_1", "source_2"])
         if first is None:
@@ -127,7 +137,46 @@ def test_three_levels_when_there_are_more_than_65536_buckets(oracle_lib, monkeyp
     assert int(sk.offsets[-1]) > 1_200_000                      # / 16 per bucket: > 65 536 buckets
     ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
     for mean in ("16", "9"):
-        hand, st = _edges(sk, monkeypatch, KSP_PART_MIN="1", KSP_DEBUG_BUCKET_MEAN=mean)
+        hand, st = _edges(sk, monkeypatch, KSP_PART_MIN="1", KSP_DEBUG_BUCKET_MEAN=mean)   # (more than 65 536 buckets: never the segment partition)
         assert st["partition_kind"] == 2 and st["partition_fallback"] == 0, st
         assert st["sort_bits"] > 16                                 # more than 2^16 buckets
         assert len(hand) == len(ref) and (hand == ref).all()
+
+
+def test_segment_partition_shapes(oracle_lib, monkeypatch):
+    """The segment partition on what it is for and around its edges: long sorted runs (chosen by the segment-length
+    rule, no switch), groups cut at 512 sources (tiny runs), empty runs between long ones, a run that ends exactly on a
+    window of the boundary scan, one bucket range that no key of a source falls into, and a hot key whose bucket
+    outgrows its fixed places (falls back, same edges)."""
+    rng = np.random.default_rng(23)
+    hmax = (1 << 64) // 1000
+    # (a) sourmash-like: 600 sources x ~4 000 hashes, clusters of 30
+    sk = synth.generate("C2", n_sources=600, mean_size=4000, cluster_cap=30, seed=77)
+    edges, st = _edges(sk, monkeypatch)
+    assert st["partition_kind"] == 3 and st["partition_fallback"] == 0, st
+    ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
+    assert len(edges) == len(ref) and (edges == ref).all()
+    # (b) thousands of tiny runs (groups end at 512 sources), empty runs, runs of exactly 256 / 512 entries, and runs
+    # whose keys all sit in the upper half of the range (boundaries crossed in one step)
+    pool = rng.integers(0, hmax, size=60_000, dtype=np.uint64)
+    runs = []
+    for s in range(2600):
+        if s % 11 == 0:
+            runs.append(np.zeros(0, dtype=np.uint64))
+        elif s % 13 == 0:
+            r = np.unique(pool[rng.integers(0, pool.size, size=700)])[:256 * (1 + s % 2)]
+            runs.append(r)
+        elif s % 7 == 0:
+            runs.append(np.unique(pool[pool > hmax // 2][rng.integers(0, 20_000, size=300)]))
+        else:
+            runs.append(np.unique(pool[rng.integers(0, pool.size, size=int(rng.integers(1, 40)))]))
+    _both(synth.from_runs(runs), monkeypatch, oracle_lib)
+    # (c) one key held by every source: its bucket needs 3 000 places, the others ~150
+    hot = np.uint64(hmax // 3)
+    runs = [np.unique(np.concatenate([rng.integers(0, hmax, size=600, dtype=np.uint64), pool[rng.integers(0, pool.size, size=40)],
+                                      np.array([hot], dtype=np.uint64)])) for _ in range(3000)]
+    sk = synth.from_runs(runs)
+    edges, st = _edges(sk, monkeypatch, KSP_PART_MIN="1", KSP_SEG="1", KSP_DEBUG_BUCKET_MEAN="150")
+    assert st["partition_kind"] == 2 and st["partition_fallback"] == 5, st        # a bucket overflowed: paged partition
+    ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
+    assert len(edges) == len(ref) and (edges == ref).all()

@@ -8,7 +8,7 @@ import sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "k_zero_regions" in r["Kernel_Name"]]
+starts = [i - 1 for i, r in enumerate(rows) if "k_prep_sources" in r["Kernel_Name"] and i > 0]   # (the build's zeroing launch precedes it)
 if len(starts) < 3:
     raise SystemExit("no steps found")
 a, b = starts[-2], starts[-1]
