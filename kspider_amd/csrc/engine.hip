@@ -122,7 +122,8 @@ struct ksp_engine {
     u32 part_min = 4096;          // entries from which the hand-written partition is used (KSP_PART_MIN)
     ksp::Buf PK, PT, PD, parena;  // level-1 pages of the partition: keys, tags, digit bytes; pools, cursors, page tables
     bool seg_off = false;         // the segment partition gave up on these keys (a tile or a bucket overflowed): paged levels
-    ksp::Buf seg_tbl, seg_grp;    // segment partition: per source the first entry of every range; first source of every group
+    ksp::Buf seg_tbl, seg_grp, seg_chk;   // segment partition: per source the first entry of every range; first source of every group; chunks of k_seg_bounds
+    std::vector<uint4> seg_chunks;
     std::vector<u32> seg_groups;  // host copy of the groups (valid while the offsets and the range count are unchanged)
     u32 seg_groups_nb1 = 0;
     bool seg_groups_ok = false;
@@ -573,17 +574,31 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                     ++cnt_s;
                 }
                 gs.push_back(N);
+                std::vector<uint4>& ck = e->seg_chunks;   // chunks of k_seg_bounds: 2 048 consecutive entries of one run each
+                ck.clear();
+                for (u32 s_ = 0; s_ < N; ++s_) {
+                    const u64 b_ = e->h_off[s_], len = e->h_off[s_ + 1] - b_;
+                    u64 a = 0;
+                    do {
+                        const u64 c = std::min<u64>(SEG_BPART, len - a);
+                        ck.push_back(make_uint4((u32)(b_ + a), (u32)a, s_, (u32)c | (a + c == len ? 0x80000000u : 0u)));
+                        a += c;
+                    } while (a < len);
+                }
+                if ((rc = e->seg_chk.ensure(ck.size() * 16))) return rc;
+                KSP_HIP(hipMemcpyAsync(e->seg_chk.p, ck.data(), ck.size() * 16, hipMemcpyHostToDevice, st));
                 e->seg_groups_nb1 = seg_nb1;
                 e->seg_groups_ok = true;
-                if ((rc = e->seg_grp.ensure(gs.size() * 4))) return rc;
+                if ((rc = e->seg_grp.ensure(gs.size() * 4 + 16 + 258 * 8))) return rc;   // (+ the ranges' first keys, k_seg_prep)
                 KSP_HIP(hipMemcpyAsync(e->seg_grp.p, gs.data(), gs.size() * 4, hipMemcpyHostToDevice, st));
             }
             const u32 ngroups_s = (u32)e->seg_groups.size() - 1;
             phase_mark(e, st, "partition");
             KSP_HIP(hipEventRecord(e->ev[4], st));
-            hipLaunchKernelGGL(k_part_src, dim3(1), dim3(64), 0, st, d_off, N, 0u, hp_src, scal, nbuckets);   // (the multiplier of this build)
-            hipLaunchKernelGGL(k_seg_bounds, dim3(N), dim3(64 * SEG_BW), 0, st, d_keys, d_off, N, scal, seg_pb2, nbuckets - 1, seg_nb1,
-                               e->seg_tbl.as<u32>());
+            u64* kmin = (u64*)((char*)e->seg_grp.p + (((e->seg_groups.size() * 4) + 15) & ~(size_t)15));   // (behind the groups)
+            hipLaunchKernelGGL(k_seg_prep, dim3(1), dim3(256), 0, st, scal, nbuckets, seg_pb2, seg_nb1, kmin);   // (the multiplier of this build, the ranges' first keys)
+            hipLaunchKernelGGL(k_seg_bounds, dim3((u32)e->seg_chunks.size()), dim3(64 * SEG_BW), 0, st, d_keys, e->seg_chk.as<uint4>(), scal, kmin,
+                               seg_pb2, nbuckets - 1, seg_nb1, e->seg_tbl.as<u32>());
             hipLaunchKernelGGL((k_seg_scatter<V>), dim3(ngroups_s * seg_nb1), dim3(P2_THREADS), 0, st, d_keys, d_off, e->seg_tbl.as<u32>(),
                                e->seg_grp.as<u32>(), scal, seg_pb2, nbuckets - 1, seg_nb1, seg_cap, hp_gcnt, KA, VB);
             KSP_HIP(hipEventRecord(e->ev[5], st));
@@ -1032,7 +1047,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
-                        &e->d_wg, &e->gp, &e->gm, &e->PK, &e->PT, &e->PD, &e->parena, &e->PK2, &e->PT2, &e->PD2, &e->seg_tbl, &e->seg_grp, &e->biglist, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
+                        &e->d_wg, &e->gp, &e->gm, &e->PK, &e->PT, &e->PD, &e->parena, &e->PK2, &e->PT2, &e->PD2, &e->seg_tbl, &e->seg_grp, &e->seg_chk, &e->biglist, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
                         &e->mr0, &e->mr1, &e->mstart};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);

@@ -495,54 +495,116 @@ constexpr u32 SEG_SMAX = 512;     // sources per group (LDS: start slot and addr
 constexpr u32 SEG_FILL = 3072;    // mean entries of a tile; the tile holds P2_TILE (uniform hashes: +18 sigma)
 constexpr u32 SEG_MIN_LEN = 12;   // mean segment length from which the path is used
 
-// one workgroup per source, a quarter of the run per wave, streamed once: where the range id steps up, the lane at the
-// step writes the boundaries it crosses (bnd[s][j] = first entry of range j or a later one; bnd[s][0] = 0,
-// bnd[s][nb1] = length).  The next windows are requested before the current ones are looked at.
-constexpr u32 SEG_BW = 4;   // waves per source
-__global__ __launch_bounds__(64 * SEG_BW) void k_seg_bounds(const u64* __restrict__ keys, const u64* __restrict__ off, const u32 n_sources,
-                                                            u64* __restrict__ scal, const int pb2, const u32 nbm1, const u32 nb1,
-                                                            u32* __restrict__ bnd) {
-    const u32 s = blockIdx.x, part = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (s >= n_sources) return;
+// the multiplier of this build and, per range j, the smallest key that belongs to range j or a later one:
+// umulhi(key, mult) >= j << pb2  <=>  key >= ceil((j << pb2) * 2^64 / mult)   (kmin[0] = 0; j << pb2 < nbuckets <= mult)
+__global__ __launch_bounds__(256) void k_seg_prep(u64* __restrict__ scal, const u32 nbuckets, const int pb2, const u32 nb1,
+                                                  u64* __restrict__ kmin) {
+    if (threadIdx.x == 0) part_prep(scal, nbuckets);
+    __threadfence_block();
+    __syncthreads();
     const u64 mult = scal[PC_MULT];
     const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
-    const u64 b = off[s];
-    const u32 len = (u32)(off[s + 1] - b);
-    const u32 a0 = (u32)(((u64)len * part) / SEG_BW), a1 = (u32)(((u64)len * (part + 1)) / SEG_BW);
-    const bool last = part == SEG_BW - 1;
+    for (u32 j = threadIdx.x; j <= nb1; j += 256) {
+        const u64 T = (u64)j << pb2;
+        u64 k = T;   // (identity buckets: bucket = min(key, nbuckets - 1))
+        if (j >= nb1) k = ~0ull;   // (sentinel: never read as a boundary)
+        else if (!ident && T) {
+            u64 rem = T, q = 0;   // (T : 0) / mult, T < mult
+            for (int i = 63; i >= 0; --i) {
+                const u64 carry = rem >> 63;
+                rem <<= 1;
+                if (carry || rem >= mult) { rem -= mult; q |= 1ull << i; }
+            }
+            k = q + (rem ? 1ull : 0ull);
+        }
+        kmin[j] = k;
+    }
+}
+
+// one workgroup (four waves) per 2 048 consecutive entries of a source (the chunks come from a host table that is
+// rebuilt when the offsets change).  Window w of the chunk goes to wave w % 4, so every load
+// instruction of the workgroup covers 2 KB of consecutive memory and all eight of a wave are requested together.  The
+// keys of a window ascend, so the window crosses the boundaries between the range of the entry in front of it (the last
+// key of the previous window: exchanged through LDS) and the range of its own last key — uniform 64 x 64 multiplies on
+// the scalar unit instead of one per key — and boundary j sits behind the keys below kmin[j]: one compare + ballot
+// each.  bnd[s][j] = first entry of range j or a later one; bnd[s][0] = 0, bnd[s][nb1] = length.
+constexpr u32 SEG_BW = 4;          // waves per workgroup
+constexpr u32 SEG_BWIN = 8;        // windows of 64 entries per wave
+constexpr u32 SEG_BPART = 64 * SEG_BWIN * SEG_BW;   // entries per workgroup
+__device__ inline u32 seg_range_of(const u64 key, const u64 mult, const u32 ident, const u32 nbm1, const int pb2) {
+    return part_bucket(key, mult, ident, nbm1) >> pb2;
+}
+__global__ __launch_bounds__(64 * SEG_BW) void k_seg_bounds(const u64* __restrict__ keys, const uint4* __restrict__ chunks,
+                                                            const u64* __restrict__ scal, const u64* __restrict__ kmin, const int pb2,
+                                                            const u32 nbm1, const u32 nb1, u32* __restrict__ bnd) {
+    __shared__ u32 s_rl[SEG_BW * SEG_BWIN + 1];   // [1 + w]: range of the last key of window w; [0]: of the entry in front of the chunk
+    __shared__ u64 s_kmin[260];                   // the boundary keys (read with a uniform address: one broadcast each)
+    __shared__ u32 s_bnd[260];                    // the boundaries this chunk crosses: they leave in one piece (single words per
+                                                  // boundary were 2 M partial-line writes per build)
+    const u32 lane = threadIdx.x & 63;
+    const u32 wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // this workgroup's chunk (host table: no empty workgroups, no offsets to fetch first):
+    // first entry in the sketch array, position inside its run, source, entries | last chunk of the run << 31
+    const uint4 ch = chunks[blockIdx.x];
+    const u64 b = (u64)ch.x - ch.y;   // start of the run
+    const u32 s = ch.z, a0 = ch.y, a1 = a0 + (ch.w & 0x7FFFFFFFu);
+    const bool last_chunk = (ch.w >> 31) != 0;
+    const u32 len = a1;   // (only used by the last chunk)
+    const u64 mult = scal[PC_MULT];
+    const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
     u32* const row = bnd + (size_t)s * (nb1 + 1);
-    if (part == 0 && lane == 0) row[0] = 0;
-    u32 carry = a0 ? (part_bucket(keys[b + a0 - 1], mult, ident, nbm1) >> pb2) : 0u;   // range of the entry in front of this part
-    constexpr u32 UN = 4;
-    u64 k[UN], kn[UN];
+    if (a0 == 0 && threadIdx.x == 0) row[0] = 0;
+    for (u32 j = threadIdx.x; j <= nb1; j += 64 * SEG_BW) s_kmin[j] = kmin[j];
+    u64 k[SEG_BWIN];
 #pragma unroll
-    for (u32 q = 0; q < UN; ++q) {
-        const u32 i = a0 + q * 64 + lane;
+    for (u32 q = 0; q < SEG_BWIN; ++q) {
+        const u32 i = a0 + (q * SEG_BW + wv) * 64 + lane;
         k[q] = i < a1 ? __builtin_nontemporal_load(keys + b + i) : 0;
     }
-    for (u32 i0 = a0; i0 < a1; i0 += 64 * UN) {
-#pragma unroll
-        for (u32 q = 0; q < UN; ++q) {
-            const u32 i = i0 + (UN + q) * 64 + lane;
-            kn[q] = i < a1 ? __builtin_nontemporal_load(keys + b + i) : 0;
+    if (wv == 0) {
+        u32 c0 = 0;
+        if (a0) {
+            const u64 kp = keys[b + a0 - 1];
+            c0 = seg_range_of((u64)(u32)__builtin_amdgcn_readfirstlane((u32)kp) | ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(kp >> 32)) << 32), mult,
+                              ident, nbm1, pb2);
         }
-#pragma unroll
-        for (u32 q = 0; q < UN; ++q) {
-            const u32 i = i0 + q * 64 + lane;
-            if (i0 + q * 64 >= a1) break;   // (uniform)
-            // the last part: entries behind the end count as range nb1 — the first of them closes every boundary still open
-            const u32 r = i < a1 ? (part_bucket(k[q], mult, ident, nbm1) >> pb2) : (last ? nb1 : 0u);
-            u32 pr = __shfl_up(r, 1);
-            if (lane == 0) pr = carry;
-            if (r > pr && (i < a1 || (last && i == a1)))
-                for (u32 j = pr + 1; j <= r; ++j) row[j] = i;
-            carry = __shfl(r, 63);
-        }
-#pragma unroll
-        for (u32 q = 0; q < UN; ++q) k[q] = kn[q];
+        if (lane == 0) s_rl[0] = c0;
     }
-    if (last && lane == 0)   // (a run that ends with a full window, or an empty one)
-        for (u32 j = carry + 1; j <= nb1; ++j) row[j] = len;
+    u32 rl[SEG_BWIN];
+#pragma unroll
+    for (u32 q = 0; q < SEG_BWIN; ++q) {
+        const u32 w = q * SEG_BW + wv, w0 = a0 + w * 64;
+        rl[q] = 0;
+        if (w0 < a1) {   // (uniform)
+            const u32 nv = min(64u, a1 - w0);
+            const u64 klast = (u64)(u32)__builtin_amdgcn_readlane((u32)k[q], nv - 1) | ((u64)(u32)__builtin_amdgcn_readlane((u32)(k[q] >> 32), nv - 1) << 32);
+            rl[q] = seg_range_of(klast, mult, ident, nbm1, pb2);
+            if (lane == 0) s_rl[1 + w] = rl[q];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 q = 0; q < SEG_BWIN; ++q) {
+        const u32 w = q * SEG_BW + wv, w0 = a0 + w * 64;
+        if (w0 >= a1) break;   // (uniform)
+        const u32 nv = min(64u, a1 - w0);
+        const unsigned long long vm = nv >= 64 ? ~0ull : (1ull << nv) - 1ull;   // valid lanes of this window
+        const u64 kl = k[q];
+        const u32 carry = __builtin_amdgcn_readfirstlane(s_rl[w]);   // range of the entry in front of this window
+        for (u32 j = carry + 1; j <= rl[q]; ++j) {   // (uniform; ranges ascend with the keys)
+            const u32 below = (u32)__popcll(__ballot(kl < s_kmin[j]) & vm);
+            if (lane == 0) s_bnd[j] = w0 + below;
+        }
+        if (w0 + 64 >= a1 && last_chunk)   // the run's last window: the ranges behind its last key are empty, they begin at the end
+            for (u32 j = rl[q] + 1 + lane; j <= nb1; j += 64) row[j] = len;
+    }
+    __syncthreads();
+    {   // boundaries (range in front of the chunk, range of its last key]: written by exactly one window each
+        const u32 c0 = s_rl[0], nw = (a1 - a0 + 63) / 64, c1 = nw ? s_rl[nw] : c0;
+        for (u32 j = c0 + 1 + threadIdx.x; j <= c1; j += 64 * SEG_BW) row[j] = s_bnd[j];
+    }
+    if (a1 == 0 && wv == 0)   // (an empty run has one chunk of no entries)
+        for (u32 j = 1 + lane; j <= nb1; j += 64) row[j] = 0;
 }
 
 // one workgroup per (group of sources, range): gather the tile from the segments, then the counting sort of k_scatter2.
