@@ -206,14 +206,57 @@ def main():
     stats = {"ms_join": 0.0, "ms_build": 0.0, "ms_sort": 0.0, "edges": 0, "stream_bytes": 0, "xchg_bytes": 0,
              "regrown": 0}
 
+    pending = [None]   # the step whose join has been launched but whose results have not been handed on yet
+
+    def hand_over(job):
+        """Rank 0 (after the gather) copies the edges of a finished join to pinned host memory on the copy stream."""
+        buf, cnt, edges_d, record = job["buf"], job["cnt"], job["edges_d"], job["record"]
+        local = edges_d[:cnt]
+        if world > 1 and backend != "nccl":
+            local = local.cpu()     # gloo exchanges host tensors (test hook only)
+        allv = kdist.gather_edges(local, dst=0) if world > 1 else local
+        if rank == 0:
+            if edges_hh[buf] is None or edges_hh[buf].shape[0] < allv.shape[0]:
+                edges_hh[buf] = torch.empty((allv.shape[0] + allv.shape[0] // 8 + 1, 16), dtype=torch.uint8).pin_memory()
+                stats["regrown"] += 1
+            edges_h = edges_hh[buf]
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(job["ready"])
+                edges_h[: allv.shape[0]].copy_(allv, non_blocking=True)
+                copied[buf] = torch.cuda.Event()
+                copied[buf].record(copy_stream)
+            in_flight[buf] = allv
+        if record:
+            stats["edges"] = int(allv.shape[0]) if rank == 0 else cnt
+            if rank == 0 and os.environ.get("KSP_BENCH_CHECKSUM") == "1":
+                copy_stream.synchronize()
+                ev = edges_hh[buf][: allv.shape[0]].numpy().view(engine.EDGE_DTYPE).reshape(-1)
+                stats["checksum"] = int(ev["shared"].sum()) ^ (int(ev["source_1"].astype(np.int64).sum()) << 20) ^ int(
+                    ev["source_2"].astype(np.int64).sum())
+
+    def collect(record_join: bool):
+        """Count of the launched join (it has finished whenever a later build on the same stream has returned)."""
+        job = pending[0]
+        if job is None:
+            return None
+        pending[0] = None
+        job["cnt"] = eng.join_wait()
+        if job["record"] and record_join:
+            stats["ms_join"] += eng.stats()["ms_join"]
+        return job
+
     def step(record: bool):
-        # stage 1; every step takes its tile range and buffer sizes from ITS OWN build (the engine's source order,
-        # and with it the tile numbering, differs from build to build)
+        # Software pipeline over the steps: the join of step k is only LAUNCHED here; the next step's stage 1 is queued
+        # behind it on the same stream, and the host collects the count and hands the edges on (gather, D2H on the copy
+        # stream) while the device is already busy — the device does not wait for the host between a join and the next
+        # build.  Every step still takes its tile range and buffer sizes from ITS OWN build (the engine's source order,
+        # and with it the tile numbering, differs from build to build).
         if sharded:   # sharded by hash range + all-gather of the block-list slices: every rank assembles the same lists
             stats["xchg_bytes"] = kdist.build_blocks_sharded(eng, keys_d.data_ptr(), sk.offsets, world, rank, dev,
                                                              stream=stream.cuda_stream)
         else:
             eng.build_blocks(keys_d.data_ptr(), sk.offsets, stream=stream.cuda_stream)
+        prev = collect(True)        # (the previous join ran in front of this build: the wait returns at once)
         cuts = eng.balanced_cuts(world)
         t0, t1 = cuts[rank], cuts[rank + 1]
         buf = step_no[0] & 1
@@ -225,40 +268,29 @@ def main():
             edges_dd[buf] = torch.empty((need + need // 8, 16), dtype=torch.uint8, device=dev)
             stats["regrown"] += 1
         edges_d = edges_dd[buf]
-        cnt = eng.join(t0, t1, edges_d.data_ptr(), edges_d.shape[0], stream=stream.cuda_stream)
-        local = edges_d[:cnt]
-        if world > 1 and backend != "nccl":
-            local = local.cpu()     # gloo exchanges host tensors (test hook only)
-        allv = kdist.gather_edges(local, dst=0) if world > 1 else local
-        if rank == 0:
-            if edges_hh[buf] is None or edges_hh[buf].shape[0] < allv.shape[0]:
-                edges_hh[buf] = torch.empty((allv.shape[0] + allv.shape[0] // 8 + 1, 16), dtype=torch.uint8).pin_memory()
-                stats["regrown"] += 1
-            edges_h = edges_hh[buf]
-            ready = torch.cuda.Event()
-            ready.record(stream)            # (the gather's kernels run on the compute stream)
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(ready)
-                edges_h[: allv.shape[0]].copy_(allv, non_blocking=True)
-                copied[buf] = torch.cuda.Event()
-                copied[buf].record(copy_stream)
-            in_flight[buf] = allv
+        eng.join_launch(t0, t1, edges_d.data_ptr(), edges_d.shape[0], stream=stream.cuda_stream)
+        ready = torch.cuda.Event()
+        ready.record(stream)
+        pending[0] = {"buf": buf, "edges_d": edges_d, "record": record, "ready": ready, "cnt": 0}
+        # ---- from here on the device is busy with this step's join ----
         if record:
             st = eng.stats()
-            stats["ms_join"] += st["ms_join"]
             stats["ms_build"] += st["ms_build"]
             stats["ms_sort"] += st["ms_sort"]
             stats["sort_entries"], stats["sort_bits"] = st["sort_entries"], st["sort_bits"]
             stats["partition_kind"] = st["partition_kind"]
-            stats["stream_bytes"] = st["last_stream_bytes"]
-            stats["edges"] = int(allv.shape[0]) if rank == 0 else cnt
             stats["active_tiles"] = int(st["n_active_tiles"])
-            if rank == 0 and os.environ.get("KSP_BENCH_CHECKSUM") == "1":
-                copy_stream.synchronize()
-                ev = edges_hh[buf][: allv.shape[0]].numpy().view(engine.EDGE_DTYPE).reshape(-1)
-                stats["checksum"] = int(ev["shared"].sum()) ^ (int(ev["source_1"].astype(np.int64).sum()) << 20) ^ int(
-                    ev["source_2"].astype(np.int64).sum())
-        return cnt
+        if prev is not None:
+            hand_over(prev)
+
+    def drain():
+        """Results of the last launched join (end of a run of steps)."""
+        job = collect(True)
+        if job is not None:
+            stats["stream_bytes"] = eng.stats()["last_stream_bytes"]
+            hand_over(job)
+            return job["cnt"]
+        return 0
 
     def barrier():
         if world > 1:
@@ -269,11 +301,17 @@ def main():
 
     for _ in range(max(args.warmup, 2)):   # (at least two: both buffer pairs get their size before the clock starts)
         step(False)
+    drain()
     stats["regrown"] = 0
     barrier()
     t_start = time.perf_counter()
+    trace = os.environ.get("KSP_BENCH_TRACE") == "1"   # (diagnostic: host time of every step's calls, on stderr)
     for _ in range(args.steps):
+        t_s = time.perf_counter()
         step(True)
+        if trace and rank == 0:
+            print(f"step {1e3 * (time.perf_counter() - t_s):.3f} ms", file=sys.stderr)
+    drain()                 # (the last step's count, gather and D2H: inside the timed region)
     barrier()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -300,6 +338,7 @@ def main():
             order = []
             for _ in range(args.profile_steps):
                 step(False)
+                drain()
                 torch.cuda.synchronize(dev)
                 for name, ms in eng.phase_times():
                     if name not in acc:

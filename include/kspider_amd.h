@@ -107,6 +107,12 @@ int ksp_engine_balanced_cuts(const ksp_engine* e, uint32_t nparts, uint64_t* cut
  * returns KSP_E_OVERFLOW.  Synchronises `stream` before returning.                      */
 int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_edge* d_edges, uint64_t capacity,
                     uint64_t* h_count, void* stream);
+/* The same in two halves, for callers that pipeline: _launch queues the join on `stream` and returns; _wait blocks
+ * until it has finished and reports the count (one launched join per engine at a time).  Work queued on the same
+ * stream after _launch — the next ksp_engine_build_blocks on this engine included — runs behind the join, so the
+ * device does not idle while the host collects the count and hands the edges on (bench.py does exactly that). */
+int ksp_engine_join_launch(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_edge* d_edges, uint64_t capacity, void* stream);
+int ksp_engine_join_wait(ksp_engine* e, uint64_t* h_count);
 
 int ksp_engine_get_stats(const ksp_engine* e, ksp_stats* out);
 /* Per-phase HIP-event times of stage 1 (the reference's own phase timers, src/pairwise.cpp:131-133,155,181,

@@ -179,6 +179,14 @@ struct ksp_engine {
     int part_fail = 0;                       // overflow word of the hand-written partition when it gave up (stats)
     u64 h_scal_words = 0, h_scal_keys = 0;   // list words / distinct shared keys of the lists being finished
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // build, join, first radix sort
+    hipEvent_t ev_join_done = nullptr;   // behind the count copy of the last ksp_engine_join_launch
+    bool join_pending = false;           // a launched join whose count has not been collected (ksp_engine_join_wait)
+    u64 join_cap = 0;
+    ksp_stats jst{};                     // last_* of the launched join
+#ifdef KSP_WGTIME
+    ksp::Buf wgt_buf;
+    size_t wgt_n = 0;
+#endif
     ksp_stats st{};
 };
 
@@ -1032,6 +1040,7 @@ int ksp_engine_create(int device, ksp_engine** out) {
     hipError_t err = hipHostMalloc((void**)&e->h_count, 64);
     if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_scal, 128);
     for (int i = 0; i < 6 && err == hipSuccess; ++i) err = hipEventCreate(&e->ev[i]);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev_join_done);
     for (int i = 0; i < ksp_engine::kMaxPhase && err == hipSuccess; ++i) err = hipEventCreate(&e->ph_ev[i]);
     if (err != hipSuccess) {
         set_error(std::string("ksp_engine_create: ") + hipGetErrorString(err));
@@ -1055,6 +1064,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->h_blk_stage) (void)hipHostFree(e->h_blk_stage);
     for (int i = 0; i < 6; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    if (e->ev_join_done) (void)hipEventDestroy(e->ev_join_done);
     for (int i = 0; i < ksp_engine::kMaxPhase; ++i) if (e->ph_ev[i]) (void)hipEventDestroy(e->ph_ev[i]);
     delete e;
 }
@@ -1097,9 +1107,11 @@ static int build_schedule(ksp_engine* e) {
     int rc;
     if ((rc = query_slots(e))) return rc;
     auto words_of = [&](u32 b) { return (u64)(e->h_blk_off[b + 1] - e->h_blk_off[b]); };
+    u64 off_cost = 24;   // (8 — the search alone — left the off-diagonal shares of C2 at twice the time of the diagonal ones: join 0.283 -> 0.246 ms)
+    if (const char* oc = std::getenv("KSP_DEBUG_OFFCOST")) off_cost = (u64)std::max(1, std::atoi(oc));   // (timing experiments)
     auto cost_of = [&](u32 I, u32 J) -> u64 {
         if (I == J && !e->weighted) return 40 * words_of(I) + 20000;   // bit-sliced: 16 popcounts x 528 patches per 64 keys
-        return I == J ? dw[I] / 2 + 10 * words_of(I) + 20000 : 8 * (words_of(I) + words_of(J)) + 20000;
+        return I == J ? dw[I] / 2 + 10 * words_of(I) + 20000 : off_cost * (words_of(I) + words_of(J)) + 20000;
     };
     // pass 1: active tiles
     u64 total = 0;
@@ -1674,15 +1686,15 @@ int ksp_engine_balanced_cuts(const ksp_engine* e, uint32_t nparts, uint64_t* cut
     return KSP_OK;
 }
 
-int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_edge* d_edges, uint64_t capacity,
-                    uint64_t* h_count, void* stream) {
-    if (!e || !h_count) { set_error("join: NULL argument"); return KSP_E_ARG; }
+int ksp_engine_join_launch(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_edge* d_edges, uint64_t capacity, void* stream) {
+    if (!e) { set_error("join: NULL argument"); return KSP_E_ARG; }
     if (!e->built) { set_error("join: build_blocks has not been run"); return KSP_E_ARG; }
     hipStream_t st = (hipStream_t)stream;
     KSP_HIP(hipSetDevice(e->device));
     const u64 T = ksp_engine_num_tiles(e);
     if (tile_end > T) tile_end = T;
-    *h_count = 0;
+    e->join_pending = false;
+    e->jst = ksp_stats{};
     e->st.last_tiles = 0; e->st.last_pairs = 0; e->st.last_edges = 0; e->st.last_stream_bytes = 0; e->st.ms_join = 0;
     if (tile_begin >= tile_end || e->n_entries == 0 || e->n_kept == 0) return KSP_OK;
     if (capacity && !d_edges) { set_error("join: d_edges is NULL"); return KSP_E_ARG; }
@@ -1715,10 +1727,11 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     a.collect = e->collect ? 1u : 0u;
     a.mrec = nullptr; a.mstart = nullptr;
 #ifdef KSP_WGTIME
-    static ksp::Buf wgt_buf;   // (timing builds only, tools/wg_times.py)
+    ksp::Buf& wgt_buf = e->wgt_buf;   // (timing builds only, tools/wg_times.py)
     a.wgt = nullptr;
     const char* wgt_file = std::getenv("KSP_WGTIME_FILE");
-    size_t wgt_n = 0;
+    size_t& wgt_n = e->wgt_n;
+    wgt_n = 0;
 #endif
     auto launch = [&](bool c16, dim3 grid, const JoinArgs& args) {
         if (e->use_cells) {
@@ -1812,20 +1825,11 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     }   // launch chunks
     KSP_HIP(hipEventRecord(e->ev[3], st));
     KSP_HIP(hipMemcpyAsync(e->h_count, a.out_count, 8, hipMemcpyDeviceToHost, st));
-    KSP_HIP(hipStreamSynchronize(st));
-    KSP_HIP(hipEventElapsedTime(&e->st.ms_join, e->ev[2], e->ev[3]));
-    *h_count = *e->h_count;
-#ifdef KSP_WGTIME
-    if (wgt_file && wgt_n) {
-        std::vector<unsigned long long> h(wgt_n * 16);
-        KSP_HIP(hipMemcpy(h.data(), wgt_buf.p, wgt_n * 128, hipMemcpyDeviceToHost));
-        if (FILE* f = std::fopen(wgt_file, "wb")) { std::fwrite(h.data(), 128, wgt_n, f); std::fclose(f); }
-    }
-#endif
-    e->st.last_tiles = tile_end - tile_begin;
-    e->st.last_active_tiles = e->sched_on ? (u64)(act1 - act0) : tile_end - tile_begin;
-    e->st.last_pairs = ksp_engine_tile_pairs(e, tile_begin, tile_end);
-    e->st.last_edges = *h_count;
+    KSP_HIP(hipEventRecord(e->ev_join_done, st));
+    // what ksp_engine_join_wait reports besides the count: known now (a build may start on this engine before the wait)
+    e->jst.last_tiles = tile_end - tile_begin;
+    e->jst.last_active_tiles = e->sched_on ? (u64)(act1 - act0) : tile_end - tile_begin;
+    e->jst.last_pairs = ksp_engine_tile_pairs(e, tile_begin, tile_end);
     {   // bytes the kernel streams from both block lists; self tiles read info [+ weight] only
         const u64 per = 4;   // only the 32-bit ranks are streamed; posting words are gathered on matches
         u64 bytes = 0;
@@ -1844,13 +1848,51 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
             if (cnt) bytes += (cnt * kI + (u64)(e->h_blk_off[J0 + cnt] - e->h_blk_off[J0])) * per;
             t = stop;
         }
-        e->st.last_stream_bytes = bytes;
+        e->jst.last_stream_bytes = bytes;
     }
-    if (*h_count > capacity) {
-        set_error("join: edge buffer too small (" + std::to_string(*h_count) + " > " + std::to_string(capacity) + ")");
+    e->join_cap = capacity;
+    e->join_pending = true;
+    return KSP_OK;
+}
+
+int ksp_engine_join_wait(ksp_engine* e, uint64_t* h_count) {
+    if (!e || !h_count) { set_error("join: NULL argument"); return KSP_E_ARG; }
+    *h_count = 0;
+    if (!e->join_pending) return KSP_OK;   // (nothing was launched: no tile in range, or no shared key at all)
+    e->join_pending = false;
+    KSP_HIP(hipSetDevice(e->device));
+    KSP_HIP(hipEventSynchronize(e->ev_join_done));
+    KSP_HIP(hipEventElapsedTime(&e->st.ms_join, e->ev[2], e->ev[3]));
+    *h_count = *e->h_count;
+    e->st.last_tiles = e->jst.last_tiles;
+    e->st.last_active_tiles = e->jst.last_active_tiles;
+    e->st.last_pairs = e->jst.last_pairs;
+    e->st.last_stream_bytes = e->jst.last_stream_bytes;
+    e->st.last_edges = *h_count;
+#ifdef KSP_WGTIME
+    if (const char* wgt_file = std::getenv("KSP_WGTIME_FILE")) {
+        const size_t wgt_n = e->wgt_n;
+        if (wgt_n) {
+            std::vector<unsigned long long> h(wgt_n * 16);
+            KSP_HIP(hipMemcpy(h.data(), e->wgt_buf.p, wgt_n * 128, hipMemcpyDeviceToHost));
+            if (FILE* f = std::fopen(wgt_file, "wb")) { std::fwrite(h.data(), 128, wgt_n, f); std::fclose(f); }
+        }
+    }
+#endif
+    if (*h_count > e->join_cap) {
+        set_error("join: edge buffer too small (" + std::to_string(*h_count) + " > " + std::to_string(e->join_cap) + ")");
         return KSP_E_OVERFLOW;
     }
     return KSP_OK;
+}
+
+int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_edge* d_edges, uint64_t capacity,
+                    uint64_t* h_count, void* stream) {
+    if (!h_count) { set_error("join: NULL argument"); return KSP_E_ARG; }
+    *h_count = 0;
+    int rc = ksp_engine_join_launch(e, tile_begin, tile_end, d_edges, capacity, stream);
+    if (rc) return rc;
+    return ksp_engine_join_wait(e, h_count);
 }
 
 int ksp_engine_set_profiling(ksp_engine* e, int on) {

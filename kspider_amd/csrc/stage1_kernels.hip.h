@@ -176,12 +176,13 @@ __global__ void k_retag(V* __restrict__ vals, const u32* __restrict__ newidx, u6
 // on where the boundaries are.
 //
 // k_pack_blocks, ONE workgroup: the distance of every sorted position to the head of its cluster goes to LDS (one
-// byte, capped), then one lane walks the chain of block starts (two or three LDS reads per block); bstart[b] = sorted
-// position where block b begins (= sources in the blocks before it), bstart[nb] = n.
-constexpr u32 PACK_MAX = 131072;   // sources (LDS bytes of the distance table)
+// byte, capped); from it every position gets, as if a block started there, where the next block would start (one byte:
+// 128 or less); then one lane walks the chain of block starts — one LDS read per block — spending the budget of holes.
+// bstart[b] = sorted position where block b begins (= sources in the blocks before it), bstart[nb] = n.
+constexpr u32 PACK_MAX = 65536;   // sources (two byte tables in LDS); larger sets keep plain cuts (blocks_for)
 __global__ __launch_bounds__(1024) void k_pack_blocks(const u32* __restrict__ labs, const u32 n, const u32 nb,
                                                       u32* __restrict__ bstart) {
-    __shared__ unsigned char s_d[PACK_MAX];
+    __shared__ unsigned char s_d[PACK_MAX], s_nx[PACK_MAX];
     __shared__ u32 s_head[1024];   // last cluster head in or before the thread's chunk, + 1 (0: none yet)
     __shared__ u32 s_used;
     const u32 tid = threadIdx.x;
@@ -209,21 +210,32 @@ __global__ __launch_bounds__(1024) void k_pack_blocks(const u32* __restrict__ la
         }
     }
     __syncthreads();
+    // a block that starts at b ends at x = b + 128 — or, when a cluster of at most 128 sources that began inside the block
+    // would straddle x, in front of that cluster: s_nx[b] = holes that costs (0: the block is full)
+    for (u32 b = tid; b < n; b += 1024) {
+        const u32 x = b + (u32)TB;
+        u32 holes = 0;
+        if (x < n) {
+            const u32 d = s_d[x];
+            if (d != 0 && d < (u32)TB) {
+                const u32 hx = x - d;
+                const bool big = hx + (u32)TB < n && s_d[hx + (u32)TB] >= (u32)TB;   // more than 128 members: no block holds it
+                if (!big) holes = d;
+            }
+        }
+        s_nx[b] = (unsigned char)holes;
+    }
+    __syncthreads();
     if (tid == 0) {
         const u32 budget = nb * (u32)TB - n;
-        u32 b = 0, k = 0, holes = 0;
+        u32 b = 0, k = 0, spent = 0;
         while (true) {
             bstart[k] = b;
-            const u32 x = b + (u32)TB;
-            if (x >= n) break;
-            u32 nx = x;
-            const u32 d = s_d[x];
-            if (d != 0 && d < (u32)TB) {            // the cluster at the end of this block began inside it ...
-                const u32 hx = x - d;
-                const bool big = hx + (u32)TB < n && s_d[hx + (u32)TB] >= (u32)TB;   // ... more than 128 members: no block holds it
-                if (!big && holes + d <= budget) { nx = hx; holes += d; }
-            }
-            b = nx;
+            if (b + (u32)TB >= n) break;
+            const u32 h = s_nx[b];
+            const bool take = h && spent + h <= budget;
+            if (take) spent += h;
+            b += (u32)TB - (take ? h : 0u);
             ++k;
         }
         s_used = k + 1;   // (<= nb: every block but the last covers 128 slots, sources + holes <= nb x 128)

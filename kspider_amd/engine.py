@@ -22,6 +22,7 @@ KSP_OK, KSP_E_ARG, KSP_E_HIP, KSP_E_IO, KSP_E_OVERFLOW, KSP_E_LIMIT = range(6)
 ABI_SYMBOLS = [
     "ksp_last_error", "ksp_device_count", "ksp_engine_create", "ksp_engine_destroy",
     "ksp_engine_build_blocks", "ksp_engine_num_tiles", "ksp_engine_tile_pairs", "ksp_engine_join",
+    "ksp_engine_join_launch", "ksp_engine_join_wait",
     "ksp_engine_get_stats", "ksp_device_malloc", "ksp_device_free", "ksp_memcpy_h2d", "ksp_memcpy_d2h",
     "ksp_pairwise_host", "ksp_free", "kspider_pairwise", "ksp_index_info", "ksp_format_float",
     "kspider_pairwise_sigs", "kspider_pairwise_bins",
@@ -322,6 +323,19 @@ class Engine:
     def edge_bound(self, t0: int, t1: int) -> int:
         """Upper bound on the edges of tiles [t0, t1): source pairs of the tiles that share a key."""
         return lib().ksp_engine_edge_bound(self._h, t0, t1)
+
+    def join_launch(self, t0: int, t1: int, d_edges_ptr: int, capacity: int, stream: int = 0) -> None:
+        """Queue the join on `stream` and return; join_wait() collects the count (see include/kspider_amd.h)."""
+        L = lib()
+        L.ksp_engine_join_launch.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        _check(L.ksp_engine_join_launch(self._h, t0, t1, d_edges_ptr or None, capacity, ctypes.c_void_p(stream)))
+
+    def join_wait(self) -> int:
+        L = lib()
+        L.ksp_engine_join_wait.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        cnt = ctypes.c_uint64(0)
+        _check(L.ksp_engine_join_wait(self._h, ctypes.byref(cnt)))
+        return int(cnt.value)
 
     def join(self, t0: int, t1: int, d_edges_ptr: int, capacity: int, stream: int = 0) -> int:
         cnt = ctypes.c_uint64(0)
