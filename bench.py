@@ -140,8 +140,8 @@ def run_other_config(cfg: str, torch, dev, engine, synth) -> dict:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: sources = N(config) * sqrt(gpus); strong: the config's own size on every GPU count")

@@ -141,6 +141,7 @@ struct ksp_engine {
     bool have_rank_pairs = false; // gp holds (block, rank) of every list word in rank order (key-by-key build)
     bool have_dwork = false;      // ... and dwork the diagonal work / holder sums (k_move_groups)
     ksp::Buf gp, gm;              // group records of the key-by-key build; parked masks
+    u64 gp_stride = 0;            // gp: gp_stride record values (u64), then as many blocks, ranks and sorted blocks (u32)
     bool reorder = true;          // order the sources by shared-key label before cutting blocks (KSP_REORDER=0: off)
     bool need32 = false;          // some tile pairs two blocks that both hold a source with >= 2^16 k-mers
     int key_bits = 64;
@@ -180,6 +181,8 @@ struct ksp_engine {
     u64 h_scal_words = 0, h_scal_keys = 0;   // list words / distinct shared keys of the lists being finished
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // build, join, first radix sort
     hipEvent_t ev_join_done = nullptr;   // behind the count copy of the last ksp_engine_join_launch
+    hipEvent_t ev_rb = nullptr;          // behind a read-back the host waits for while later kernels are already queued
+    double kept_frac = 0.7;              // kept / all entries of the previous build (label sampling before the count is known)
     bool join_pending = false;           // a launched join whose count has not been collected (ksp_engine_join_wait)
     u64 join_cap = 0;
     ksp_stats jst{};                     // last_* of the launched join
@@ -193,6 +196,15 @@ struct ksp_engine {
 namespace ksp {
 
 static inline unsigned grid_for(u64 n, unsigned bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// wait for the read-back behind which e->ev_rb was recorded (later kernels may already be queued on the stream)
+static inline hipError_t wait_readback(ksp_engine* e) {
+    static const int mode = [] { const char* m = std::getenv("KSP_DEBUG_RBWAIT"); return m ? std::atoi(m) : 0; }();
+    if (mode == 1) return hipEventSynchronize(e->ev_rb);
+    hipError_t err;
+    while ((err = hipEventQuery(e->ev_rb)) == hipErrorNotReady) {}
+    return err;
+}
 
 // Blocks of a build.  With the source reordering on, half as many again as the sources need: the spare slots let
 // clusters of up to 128 related sources start a block instead of straddling two (k_pack_blocks); what is not needed
@@ -312,13 +324,13 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     u32 label_max = std::max<u32>(256, N / 16);   // holders above which a key is ignored by the label pass
     if (const char* lm = std::getenv("KSP_DEBUG_LABEL_MAX")) label_max = (u32)std::max(1, std::atoi(lm));
     // the label pass over the kept keys (first[] = where each key's entries start); KB is free whenever it runs
-    auto run_label = [&](const u32* firstp, const u32 n_keys, const u64 kept) {
+    auto run_label = [&](const u32* firstp, const u32 n_keys, const u64 kept, const u64* scal_dev = nullptr) {
         const u32 skip = label_sampling(e, kept);
         const int ls = e->KB.bytes >= (size_t)N * 128 ? 5 : 0;
         u32* lab = ls ? (u32*)e->KB.p : label;
         if (ls) hipLaunchKernelGGL(k_label_spread, dim3(grid_for(N, bs)), dim3(bs), 0, st, lab, ls, N);
         hipLaunchKernelGGL((k_label<V>), dim3(grid_for(n_keys / (skip + 1) + 1, bs)), dim3(bs), 0, st, VA, firstp, lab, ls,
-                           skip, label_max, n_keys);
+                           skip, label_max, n_keys, scal_dev);
         if (ls) hipLaunchKernelGGL(k_label_gather, dim3(grid_for(N, bs)), dim3(bs), 0, st, lab, ls, label, N);
     };
     int bbits = 1;
@@ -529,6 +541,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     }
     e->n_kept = 0;
     m = 0;
+    bool labels_queued = false;   // the label pass was queued before the grouping's counts were read back
     if (nw == 0) return KSP_OK;   // (slice mode only) no key of this range: labels stay the identity
     // sort 1: all entries by the top 32 significant key bits (payload = tag [+weight]):
     // d_keys,VA -> KA,VB; then order the rare mixed runs by the full key (k_fix_runs)
@@ -683,7 +696,18 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         hipLaunchKernelGGL((k_bucket_big<V, 1>), dim3(1024), dim3(HB_THREADS), 0, st, KA, VB, bb, big_list, d_hovf,
                            bsum, bbase, VA, rank1, first);
         KSP_HIP(hipMemcpyAsync(e->h_scal, scal, 120, hipMemcpyDeviceToHost, st));   // [0] max key, [2] keys, [6] entries, [9] / [14] overflow (one copy)
-        KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
+        // the kept-entry count sizes every later pass — but the label pass can be queued without it (its key count
+        // comes from the device, its sampling rate from the kept fraction of the engine's previous build), so the
+        // device works on while the host waits for the copy above
+        if (reorder) {
+            KSP_HIP(hipEventRecord(e->ev_rb, st));
+            phase_mark(e, st, "source labels + order");
+            run_label(first, (u32)std::min<u64>(nw / 2 + 1, 0x7FFFFFFFu), (u64)((double)nw * e->kept_frac), scal);
+            labels_queued = true;
+            KSP_HIP(wait_readback(e));
+        } else {
+            KSP_HIP(hipStreamSynchronize(st));
+        }
         if (hand) {
             if (seg && (u32)e->h_scal[PC_OVF]) {   // a tile or a bucket of the segment partition overflowed: the paged levels from now on
                 e->seg_off = true;
@@ -741,8 +765,9 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     }
     m = e->h_scal[6];
     e->n_kept = m;
+    if (nw) e->kept_frac = std::max(0.05, (double)m / (double)nw);
     if (m == 0 && phase == 0) return KSP_OK;   // no key is shared by two sources: no pair at all
-    if (reorder && m) {
+    if (reorder && m && !labels_queued) {
         // label = smallest source id among the holders of a source's shared keys
         phase_mark(e, st, "source labels + order");
         run_label(first, (u32)e->h_scal[2], m);
@@ -801,20 +826,19 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         if ((rc = e->tmp.ensure(tb))) return rc;
         KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
         hipLaunchKernelGGL(k_group_totals, dim3(1), dim3(64), 0, st, gsum, goff, scal, U);
-        // the number of groups sizes everything after (one 8-byte read-back pays for itself)
+        // the number of groups sizes the sort of the groups and what follows; the records themselves are packed (k_move_groups)
+        // while the host waits for it: their arrays take the bound K <= m
         KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 88, hipMemcpyDeviceToHost, st));   // [1] groups ... [11] overflow (one copy)
-        KSP_HIP(hipStreamSynchronize(st));
-        if ((u32)e->h_scal[11]) {
-            e->key_groups_off = true;   // a key with thousands of holders: this engine sorts by block from now on
-        } else {
-            const u64 K = std::max<u64>(1, e->h_scal[1]);
-            if ((rc = e->gp.ensure((K + 4) * 20))) return rc;
-            u64* rec_val = e->gp.as<u64>();
-            u32 *rec_blk = (u32*)(rec_val + (K + 4)), *rec_rank = rec_blk + (K + 4), *sblk = rec_rank + (K + 4);
-            u64* sval = (u64*)KA;             // (the per-key counts and offsets are dead once the records are packed)
+        KSP_HIP(hipEventRecord(e->ev_rb, st));
+        const u64 Kcap = m;
+        if ((rc = e->gp.ensure((Kcap + 4) * 20))) return rc;
+        e->gp_stride = Kcap + 4;
+        u64* rec_val = e->gp.as<u64>();
+        u32 *rec_blk = (u32*)(rec_val + (Kcap + 4)), *rec_rank = rec_blk + (Kcap + 4), *sblk = rec_rank + (Kcap + 4);
+        unsigned long long* work = nullptr;
+        {
             // (the diagonal work and holder sums of the join's schedule come with the move when the blocks fit its LDS table)
             phase_mark(e, st, "block lists");
-            unsigned long long* work = nullptr;
             if (nb <= KG_WORK && phase != 2) {
                 if ((rc = e->dwork.ensure(((size_t)nb + 2) * 8))) return rc;
                 if (!e->pre_zeroed_work) KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
@@ -825,11 +849,21 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             if (const char* mc = std::getenv("KSP_DEBUG_MOVE_GRID")) mg_cap = (u32)std::max(1, std::atoi(mc));   // (timing experiments)
             hipLaunchKernelGGL(k_move_groups, dim3(std::min<u32>(grid_for(U, bs), mg_cap)), dim3(bs), 0, st, gsum, goff, firstp,
                                blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, rec_blk, rec_val, rec_rank, e->mm.as<uint4>(),
-                               U, work, nb);
+                               U, work, nb, d_kovf);
+        }
+        KSP_HIP(wait_readback(e));
+        if ((u32)e->h_scal[11]) {
+            e->key_groups_off = true;   // a key with thousands of holders: this engine sorts by block from now on
+        } else {
+            const u64 K = std::max<u64>(1, e->h_scal[1]);
+            u64* sval = (u64*)KA;             // (the per-key counts and offsets are dead once the records are packed)
             e->have_dwork = work != nullptr;
+            tb = 0;   // (temporary storage for the bound, not for this build's K: K moves a little from build to build — the labels'
+                      //  atomics race — and a buffer that has to grow in the middle of a build costs a device-wide stall)
+            KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)Kcap, 0, bbits, st));
+            if ((rc = e->tmp.ensure(tb))) return rc;
             tb = 0;
             KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
-            if ((rc = e->tmp.ensure(tb))) return rc;
             KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
             if (nb <= BRP_MAX) {
                 hipLaunchKernelGGL(k_blk_raw_pos, dim3(1), dim3(1024), 0, st, sblk, (u32)e->h_scal[1], blk_raw, blk_pos, scal, nb);
@@ -936,7 +970,7 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     }
     u32 *pr = ranked ? nullptr : (u32*)e->KA.p, *pb = ranked ? nullptr : pr + (K + 4);
     // (gp: K + 4 record values, then the blocks, then the ranks — see build_impl)
-    u32 *pr2 = ranked ? e->gp.as<u32>() + 3 * (K + 4) : (u32*)e->KB.p, *pb2 = ranked ? e->gp.as<u32>() + 2 * (K + 4) : pr2 + (K + 4);
+    u32 *pr2 = ranked ? e->gp.as<u32>() + 3 * e->gp_stride : (u32*)e->KB.p, *pb2 = ranked ? e->gp.as<u32>() + 2 * e->gp_stride : pr2 + (K + 4);
     unsigned char* flags = (unsigned char*)e->tbits.p + bit_words * 4;
     phase_mark(e, st, "work list");
     if (!e->pre_zeroed_bits) KSP_HIP(hipMemsetAsync(e->tbits.p, 0, bit_words * 4 + T + 64, st));
@@ -1041,6 +1075,7 @@ int ksp_engine_create(int device, ksp_engine** out) {
     if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_scal, 128);
     for (int i = 0; i < 6 && err == hipSuccess; ++i) err = hipEventCreate(&e->ev[i]);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_join_done);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_rb, hipEventDisableTiming);
     for (int i = 0; i < ksp_engine::kMaxPhase && err == hipSuccess; ++i) err = hipEventCreate(&e->ph_ev[i]);
     if (err != hipSuccess) {
         set_error(std::string("ksp_engine_create: ") + hipGetErrorString(err));
@@ -1065,6 +1100,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     if (e->h_blk_stage) (void)hipHostFree(e->h_blk_stage);
     for (int i = 0; i < 6; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     if (e->ev_join_done) (void)hipEventDestroy(e->ev_join_done);
+    if (e->ev_rb) (void)hipEventDestroy(e->ev_rb);
     for (int i = 0; i < ksp_engine::kMaxPhase; ++i) if (e->ph_ev[i]) (void)hipEventDestroy(e->ph_ev[i]);
     delete e;
 }

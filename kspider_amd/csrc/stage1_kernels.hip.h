@@ -84,7 +84,13 @@ __global__ void k_iota4(u32* __restrict__ p0, u32* __restrict__ p1, u32* __restr
 __device__ inline u32 src_of_tag(u32 t) { return (t >> 8) * TB + (t & 0xFFu); }
 template <class V>
 __global__ void k_label(const V* __restrict__ vals, const u32* __restrict__ first, u32* __restrict__ label,
-                        const int lshift, const u32 skip, const u32 max_holders, u32 n_keys) {
+                        const int lshift, const u32 skip, const u32 max_holders, u32 n_keys, const u64* __restrict__ scal) {
+    // scal != NULL: launched before the host has read the grouping's results back — the key count comes from the
+    // device (n_keys is an upper bound) and nothing is touched when the grouping gave up (the build is repeated)
+    if (scal) {
+        if ((u32)scal[9] | (u32)scal[14]) return;
+        n_keys = min(n_keys, (u32)scal[2]);
+    }
     const u32 r = (blockIdx.x * blockDim.x + threadIdx.x) * (skip + 1);   // one thread per sampled key (skip = 2^k - 1)
     if (r >= n_keys) return;
     const u32 f0 = first[r], f1 = first[r + 1];   // (first[] has a sentinel: first[U] = number of entries)
@@ -1001,8 +1007,9 @@ __global__ __launch_bounds__(256) void k_move_groups(const u64* __restrict__ gsu
                                                      const uint4* __restrict__ tmp_mask, u32* __restrict__ rec_blk,
                                                      u64* __restrict__ rec_val, u32* __restrict__ rec_rank,
                                                      uint4* __restrict__ bigmask, u32 n_keys,
-                                                     unsigned long long* __restrict__ work, u32 nb) {
+                                                     unsigned long long* __restrict__ work, u32 nb, const u32* __restrict__ ovf) {
     __shared__ unsigned long long s_work[KG_WORK + 1];
+    if (*ovf) return;   // (queued before the host knew: a key with too many holders — the build sorts the entries by block instead)
     if (work) {
         for (u32 i = threadIdx.x; i <= nb; i += blockDim.x) s_work[i] = 0;
         __syncthreads();
