@@ -141,6 +141,7 @@ struct ksp_engine {
     bool have_rank_pairs = false; // gp holds (block, rank) of every list word in rank order (key-by-key build)
     bool have_dwork = false;      // ... and dwork the diagonal work / holder sums (k_move_groups)
     ksp::Buf gp, gm;              // group records of the key-by-key build; parked masks
+    bool scal_fresh = false;      // h_scal[1 .. 11] hold the finished build's values (read back before its last kernels were queued)
     u64 gp_stride = 0;            // gp: gp_stride record values (u64), then as many blocks, ranks and sorted blocks (u32)
     bool reorder = true;          // order the sources by shared-key label before cutting blocks (KSP_REORDER=0: off)
     bool need32 = false;          // some tile pairs two blocks that both hold a source with >= 2^16 k-mers
@@ -270,6 +271,25 @@ __global__ void k_zero_regions(const ZeroList z) {
     for (int r = 0; r < z.n; ++r)
         for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < z.words[r]; i += gridDim.x * blockDim.x) z.p[r][i] = 0;
 }
+// several small device arrays to pinned host memory by ONE launch (the kernel stores straight into the mapped host
+// buffer; every runtime copy is a dispatch of its own, and a build ended with six of them in a row)
+struct CopyList {
+    const u32* src[4];
+    u32* dst[4];
+    u32 words[4];
+    int n;
+};
+__global__ void k_copy_regions(const CopyList c) {
+    for (int r = 0; r < c.n; ++r)
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < c.words[r]; i += gridDim.x * blockDim.x) c.dst[r][i] = c.src[r][i];
+}
+static inline void copy_add(CopyList& c, const void* src, void* dst, size_t bytes) {
+    if (!bytes) return;
+    c.src[c.n] = (const u32*)src;
+    c.dst[c.n] = (u32*)dst;
+    c.words[c.n] = (u32)((bytes + 3) / 4);
+    ++c.n;
+}
 static inline void zero_add(ZeroList& z, void* p, size_t bytes) {
     if (!bytes) return;
     z.p[z.n] = (u32*)p;
@@ -333,6 +353,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                            skip, label_max, n_keys, scal_dev);
         if (ls) hipLaunchKernelGGL(k_label_gather, dim3(grid_for(N, bs)), dim3(bs), 0, st, lab, ls, label, N);
     };
+    bool hand_zeroed = false;   // this build began with the hand-written partition's zeroing launch (the whole scalar block)
     int bbits = 1;
     while ((1u << bbits) < nb) ++bbits;
     size_t tb = 0;
@@ -472,6 +493,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         }
         phase_mark(e, st, "key range + source sizes");
         hipLaunchKernelGGL(k_zero_regions, dim3(256), dim3(256), 0, st, z);
+        hand_zeroed = true;
         hipLaunchKernelGGL(k_prep_sources, dim3(grid_for(N, bs)), dim3(bs), 0, st, d_keys, d_off, (unsigned long long*)scal, sbound,
                            iota, order, newidx, label, N);
     } else {
@@ -812,7 +834,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         u32* d_kovf = (u32*)(scal + 11);
         const u32 chunks = (u32)((m + KG_CHUNK - 1) / KG_CHUNK);
         phase_mark(e, st, "key groups");
-        KSP_HIP(hipMemsetAsync(d_kovf, 0, 8, st));
+        if (!(hand_zeroed && phase == 0)) KSP_HIP(hipMemsetAsync(d_kovf, 0, 8, st));   // (the hand-written partition's build zeroes the whole scalar block at its start)
         if (phase == 3) KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input only — are visited by no chunk)
         hipLaunchKernelGGL((k_key_groups<V, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, rank1, firstp, newidx, (u32)m, U,
                            gsum, blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf,
@@ -885,6 +907,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             hipLaunchKernelGGL(k_cidx, dim3(grid_for((u64)nb * (e->ncell + 1), bs)), dim3(bs), 0, st, e->bkeys.as<u32>(),
                                blk_raw, blk_pos, scal, e->part.as<u32>(), nb, e->ncell);
             KSP_HIP(hipGetLastError());
+            e->scal_fresh = phase == 0;   // (h_scal[1] .. [11] are this build's: build_common need not fetch them again)
             e->have_rank_pairs = true;   // rec_rank / rec_blk: (rank, block) of every list word in rank order
             return KSP_OK;
         }
@@ -1036,8 +1059,12 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
         KSP_HIP(hipHostMalloc((void**)&e->h_stage, stage_bytes + stage_bytes / 4 + 4096));
         e->h_stage_bytes = stage_bytes + stage_bytes / 4 + 4096;
     }
-    KSP_HIP(hipMemcpyAsync(e->h_stage, e->dwork.p, ((size_t)nb + 2) * 8, hipMemcpyDeviceToHost, st));
-    KSP_HIP(hipMemcpyAsync(e->h_stage + ((size_t)nb + 2) * 8, e->tbits.p, bit_words * 4, hipMemcpyDeviceToHost, st));
+    {
+        CopyList c{};
+        copy_add(c, e->dwork.p, e->h_stage, ((size_t)nb + 2) * 8);
+        copy_add(c, e->tbits.p, e->h_stage + ((size_t)nb + 2) * 8, bit_words * 4);
+        hipLaunchKernelGGL(k_copy_regions, dim3(64), dim3(256), 0, st, c);
+    }
     KSP_HIP(hipGetLastError());
     e->have_bits = true;
     return KSP_OK;
@@ -1244,8 +1271,12 @@ static int stage_block_tables(ksp_engine* e, hipStream_t st) {
         e->h_blk_stage_bytes = 3 * bytes + 4096;
     }
     // [maxima | sources before every block (padded layouts)], then the list offsets
-    KSP_HIP(hipMemcpyAsync(e->h_blk_stage, e->blk_max.p, e->padded ? 2 * bytes : bytes, hipMemcpyDeviceToHost, st));
-    KSP_HIP(hipMemcpyAsync(e->h_blk_stage + 2 * bytes, e->blk_raw.p, bytes, hipMemcpyDeviceToHost, st));
+    {
+        CopyList c{};
+        copy_add(c, e->blk_max.p, e->h_blk_stage, e->padded ? 2 * bytes : bytes);
+        copy_add(c, e->blk_raw.p, e->h_blk_stage + 2 * bytes, bytes);
+        hipLaunchKernelGGL(k_copy_regions, dim3(16), dim3(256), 0, st, c);
+    }
     e->blk_staged = true;
     return KSP_OK;
 }
@@ -1361,10 +1392,13 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     if ((rc = e->blk_max.ensure((2 * (size_t)e->nb + 4) * 4))) return rc;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const int phase = slice ? 1 : 0;   // a slice stops at the source labels (ksp_engine_slice_finish does the rest)
+        e->scal_fresh = false;
         rc = build_dispatch(e, d_keys, d_weights, st, phase);
         if (rc) return rc;
-        KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 64, hipMemcpyDeviceToHost, st));
-        KSP_HIP(hipStreamSynchronize(st));
+        if (!e->scal_fresh) {   // (the key-by-key list build has read [1] .. [11] back already: nothing changes them after)
+            KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 64, hipMemcpyDeviceToHost, st));
+            KSP_HIP(hipStreamSynchronize(st));
+        }
         if ((u32)e->h_scal[4] == 0) break;
         // pathological key distribution (thousands of distinct keys share their top 32 bits):
         // redo with a full-width sort and remember it for later builds on this engine
