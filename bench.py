@@ -348,9 +348,13 @@ def main():
             eng.set_profiling(False)
             kept = None
             # bytes each group has to move per step; None where no simple model applies
-            hand = stats.get("partition_kind") == 2
+            kind = stats.get("partition_kind")
             model = {
-                "partition": n_hashes * ((8 + 8 + tag_b + 1) + (1 + 8 + tag_b) + (8 + tag_b)) if hand
+                # 3: segment partition (boundary pass reads the keys, the scatter reads them again and writes key + tag);
+                # 2: paged levels (level 1 reads keys, writes key + tag + digit; level 2 reads digit, key + tag, writes key + tag);
+                # else the library's radix passes
+                "partition": n_hashes * (8 + 8 + (8 + tag_b)) if kind == 3
+                else n_hashes * ((8 + 8 + tag_b + 1) + (1 + 8 + tag_b) + (8 + tag_b)) if kind == 2
                 else n_hashes * ((8 + tag_b) * 2 * ((int(stats.get("sort_bits", 16)) + 7) // 8) + 8),
                 "bucket grouping": n_hashes * (8 + 4 + 4 + tag_b),
                 "tags + source sizes": n_hashes * tag_b,

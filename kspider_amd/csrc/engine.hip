@@ -172,6 +172,9 @@ struct ksp_engine {
     bool blk_staged = false;
     bool d_off_sketch = false;          // d_off holds the sketch offsets of h_off (an unchanged set is not uploaded again)
     std::vector<u32> wg_host;           // share -> active tile (kept alive for the asynchronous upload)
+    u32* h_sched = nullptr;             // pinned: a small work list (records, then shares) the join reads in place — no upload
+    size_t h_sched_words = 0;
+    bool sched_in_host = false;
     std::vector<u32> h_mstart;          // match-list mode: first record of every active tile (+ sentinel)
     unsigned long long* h_count = nullptr;   // pinned
     u64* h_scal = nullptr;                   // pinned: [0] max key, [1] Ktot, [2] U
@@ -1123,6 +1126,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
+    if (e->h_sched) (void)hipHostFree(e->h_sched);
     if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->h_blk_stage) (void)hipHostFree(e->h_blk_stage);
     for (int i = 0; i < 6; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
@@ -1246,10 +1250,26 @@ static int build_schedule(ksp_engine* e) {
     }
     u32* r = &e->act_rec[4 * A];
     r[0] = 0; r[1] = 0; r[2] = (u32)wg.size(); r[3] = nsplit;
-    if ((rc = e->d_act.ensure(e->act_rec.size() * 4))) return rc;
-    if ((rc = e->d_wg.ensure(std::max<size_t>(1, wg.size()) * 4))) return rc;
-    KSP_HIP(hipMemcpyAsync(e->d_act.p, e->act_rec.data(), e->act_rec.size() * 4, hipMemcpyHostToDevice, e->sched_stream));
-    if (!wg.empty()) KSP_HIP(hipMemcpyAsync(e->d_wg.p, wg.data(), wg.size() * 4, hipMemcpyHostToDevice, e->sched_stream));
+    // a work list of a few KB stays in pinned host memory and the join's workgroups read their record from there (two
+    // uploads = two more dispatches between the build and the join otherwise); larger ones go to the device
+    e->sched_in_host = false;
+    const size_t sched_words = e->act_rec.size() + wg.size();
+    if (!e->matches_on && sched_words <= 16384) {
+        if (e->h_sched_words < sched_words) {
+            if (e->h_sched) (void)hipHostFree(e->h_sched);
+            e->h_sched = nullptr; e->h_sched_words = 0;
+            KSP_HIP(hipHostMalloc((void**)&e->h_sched, 16384 * 4));
+            e->h_sched_words = 16384;
+        }
+        std::memcpy(e->h_sched, e->act_rec.data(), e->act_rec.size() * 4);
+        if (!wg.empty()) std::memcpy(e->h_sched + e->act_rec.size(), wg.data(), wg.size() * 4);
+        e->sched_in_host = true;
+    } else {
+        if ((rc = e->d_act.ensure(e->act_rec.size() * 4))) return rc;
+        if ((rc = e->d_wg.ensure(std::max<size_t>(1, wg.size()) * 4))) return rc;
+        KSP_HIP(hipMemcpyAsync(e->d_act.p, e->act_rec.data(), e->act_rec.size() * 4, hipMemcpyHostToDevice, e->sched_stream));
+        if (!wg.empty()) KSP_HIP(hipMemcpyAsync(e->d_wg.p, wg.data(), wg.size() * 4, hipMemcpyHostToDevice, e->sched_stream));
+    }
     e->sched_on = true;
     e->st.n_active_tiles = A;
     e->st.n_match_records = e->matches_on ? e->n_matches : 0;
@@ -1823,8 +1843,8 @@ int ksp_engine_join_launch(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end
         act1 = std::lower_bound(e->act_tid.begin(), e->act_tid.end(), tile_end) - e->act_tid.begin();
         const u32 wgA = e->act_rec[4 * act0 + 2], wgB = e->act_rec[4 * act1 + 2];
         const u32 spA = e->act_rec[4 * act0 + 3], spB = e->act_rec[4 * act1 + 3];
-        a.sched = e->d_wg.as<u32>();
-        a.act = e->d_act.as<u32>();
+        a.sched = e->sched_in_host ? e->h_sched + e->act_rec.size() : e->d_wg.as<u32>();
+        a.act = e->sched_in_host ? e->h_sched : e->d_act.as<u32>();
         if (e->matches_on) { a.mrec = e->mr1.as<u64>(); a.mstart = e->mstart.as<u32>(); }
         a.split0 = spA;
         a.n_normal = 0; a.tail_sp = 1;
