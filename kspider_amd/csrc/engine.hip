@@ -140,7 +140,7 @@ struct ksp_engine {
     bool key_groups_off = false;  // a key has too many holders for the key-by-key list build: sort the entries by block
     bool have_rank_pairs = false; // gp holds (block, rank) of every list word in rank order (key-by-key build)
     bool have_dwork = false;      // ... and dwork the diagonal work / holder sums (k_move_groups)
-    ksp::Buf gp, gm;              // group records of the key-by-key build; parked masks
+    ksp::Buf gp, gm, ms_hist;     // group records of the key-by-key build; parked masks; per-chunk block counts of the split (k_ms_*)
     bool scal_fresh = false;      // h_scal[1 .. 11] hold the finished build's values (read back before its last kernels were queued)
     u64 gp_stride = 0;            // gp: gp_stride record values (u64), then as many blocks, ranks and sorted blocks (u32)
     bool reorder = true;          // order the sources by shared-key label before cutting blocks (KSP_REORDER=0: off)
@@ -883,22 +883,35 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             const u64 K = std::max<u64>(1, e->h_scal[1]);
             u64* sval = (u64*)KA;             // (the per-key counts and offsets are dead once the records are packed)
             e->have_dwork = work != nullptr;
-            tb = 0;   // (temporary storage for the bound, not for this build's K: K moves a little from build to build — the labels'
-                      //  atomics race — and a buffer that has to grow in the middle of a build costs a device-wide stall)
-            KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)Kcap, 0, bbits, st));
-            if ((rc = e->tmp.ensure(tb))) return rc;
-            tb = 0;
-            KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
-            KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
-            if (nb <= BRP_MAX) {
-                hipLaunchKernelGGL(k_blk_raw_pos, dim3(1), dim3(1024), 0, st, sblk, (u32)e->h_scal[1], blk_raw, blk_pos, scal, nb);
+            const char* msv = std::getenv("KSP_MS");   // 0: the library sort (diagnostic / tests)
+            if (nb <= MS_MAXB && K <= (u64)256 * MS_PER * MS_CHUNK && !(msv && std::atoi(msv) == 0)) {
+                // stable split of the records on the block id, written straight into the padded lists (stage1_kernels: k_ms_*)
+                const u32 chunks_cap = grid_for(Kcap, MS_CHUNK), chunks = grid_for(K, MS_CHUNK);
+                if ((rc = e->ms_hist.ensure(((size_t)chunks_cap + 1) * MS_MAXB * 4))) return rc;
+                hipLaunchKernelGGL(k_ms_hist, dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, scal, e->ms_hist.as<u32>());
+                hipLaunchKernelGGL(k_ms_scan, dim3(nb), dim3(256), 0, st, e->ms_hist.as<u32>(), scal, e->ms_hist.as<u32>() + (size_t)chunks_cap * MS_MAXB, blk_raw,
+                                   blk_pos, nb);
+                hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
+                hipLaunchKernelGGL((k_ms_place<W>), dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, rec_val, scal, e->ms_hist.as<u32>(),
+                                   blk_pos, nb, wkey, e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr);
             } else {
-                hipLaunchKernelGGL(k_blk_raw_groups, dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, sblk, (u32)e->h_scal[1], blk_raw, nb);
-                hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, blk_raw, blk_pos, scal, nb);
+            tb = 0;   // (temporary storage for the bound, not for this build's K: K moves a little from build to build — the labels'
+                          //  atomics race — and a buffer that has to grow in the middle of a build costs a device-wide stall)
+                KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)Kcap, 0, bbits, st));
+                if ((rc = e->tmp.ensure(tb))) return rc;
+                tb = 0;
+                KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
+                KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
+                if (nb <= BRP_MAX) {
+                    hipLaunchKernelGGL(k_blk_raw_pos, dim3(1), dim3(1024), 0, st, sblk, (u32)e->h_scal[1], blk_raw, blk_pos, scal, nb);
+                } else {
+                    hipLaunchKernelGGL(k_blk_raw_groups, dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, sblk, (u32)e->h_scal[1], blk_raw, nb);
+                    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, blk_raw, blk_pos, scal, nb);
+                }
+                hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
+                hipLaunchKernelGGL((k_place_groups<W>), dim3(grid_for(K, bs)), dim3(bs), 0, st, sblk, sval, blk_raw, blk_pos, wkey,
+                                   e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, (u32)e->h_scal[1]);
             }
-            hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
-            hipLaunchKernelGGL((k_place_groups<W>), dim3(grid_for(K, bs)), dim3(bs), 0, st, sblk, sval, blk_raw, blk_pos, wkey,
-                               e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, (u32)e->h_scal[1]);
             {   // the fine cell index was sized from the raw entries of a block; the lists are an order of magnitude shorter
                 // (pruned, one word per key and block): ~32 words of an average list x 4 per cell is as fine as the join
                 // ever looks (it merges cells up to ~216 keys anyway) — 16 x fewer bisections on C2 (32 -> 4 us)
@@ -1121,7 +1134,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
-                        &e->d_wg, &e->gp, &e->gm, &e->PK, &e->PT, &e->PD, &e->parena, &e->PK2, &e->PT2, &e->PD2, &e->seg_tbl, &e->seg_grp, &e->seg_chk, &e->biglist, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
+                        &e->d_wg, &e->gp, &e->gm, &e->ms_hist, &e->PK, &e->PT, &e->PD, &e->parena, &e->PK2, &e->PT2, &e->PD2, &e->seg_tbl, &e->seg_grp, &e->seg_chk, &e->biglist, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
                         &e->mr0, &e->mr1, &e->mstart};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);

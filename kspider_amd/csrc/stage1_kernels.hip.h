@@ -1112,6 +1112,142 @@ __global__ void k_place_groups(const u32* __restrict__ sblk, const u64* __restri
     if (W) bw[dst] = wkey[(u32)(v >> 32)];
 }
 
+// ---- the groups to their blocks without a library sort (up to 256 blocks) ------------------------------------------
+// The group records leave k_move_groups in rank order; the block lists want them by block, ranks ascending: a stable
+// split on the block id.  The library's radix sort took six dispatches for it (fills, histogram, scan, one pass) and
+// then two more kernels found the block bounds and placed the sorted records; here a chunk of 2 048 consecutive
+// records is counted per block (k_ms_hist), one workgroup turns the counts into every chunk's first place inside every
+// block and into the block tables (k_ms_scan: what k_blk_raw_pos searched for), and k_ms_place ranks the records of its
+// chunk — equal blocks inside a wave by eight ballots, waves and rounds through a small LDS table — and writes ranks
+// and posting words straight into the padded lists.
+constexpr u32 MS_CHUNK = 2048, MS_THREADS = 256, MS_ROUNDS = MS_CHUNK / MS_THREADS, MS_MAXB = 256;
+__global__ __launch_bounds__(MS_THREADS) void k_ms_hist(const u32* __restrict__ rec_blk, u64* __restrict__ scal,
+                                                         u32* __restrict__ hist) {
+    __shared__ u32 s_h[MS_MAXB];
+    const u32 n = (u32)scal[1];   // groups (k_group_totals)
+    const u32 g0 = blockIdx.x * MS_CHUNK;
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<u32*>(scal + 15)[0] = 0;   // k_ms_scan's "workgroups done"
+    if (g0 >= n) return;
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    for (u32 k = 0; k < MS_ROUNDS; ++k) {
+        const u32 g = g0 + k * MS_THREADS + threadIdx.x;
+        if (g < n) atomicAdd(&s_h[rec_blk[g] & (MS_MAXB - 1)], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)blockIdx.x * MS_MAXB + threadIdx.x] = s_h[threadIdx.x];
+}
+// hist[c][b] -> groups of block b in the chunks before c; blk_raw / blk_pos as k_blk_raw_pos leaves them.  One
+// workgroup per block: every thread takes up to 16 consecutive chunks of the block's column (all loads in flight), the
+// workgroup scans the thread sums, the running sums go back; the workgroup that finishes last (a counter in the
+// scalar block, zeroed by k_ms_hist) lays out the block tables.
+constexpr u32 MS_PER = 16;   // chunks per thread: 256 x 16 x 2 048 = 8.4 M groups (more: the library sort)
+__global__ __launch_bounds__(256) void k_ms_scan(u32* __restrict__ hist, u64* __restrict__ scal, u32* __restrict__ tot,
+                                                 u32* __restrict__ blk_raw, u32* __restrict__ blk_pos, const u32 nb) {
+    __shared__ u32 s_w[4], s_last;
+    const u32 n = (u32)scal[1];
+    const u32 chunks = (n + MS_CHUNK - 1) / MS_CHUNK, per = (chunks + 255u) / 256u;   // (<= MS_PER: checked by the host)
+    const u32 b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    u32 h[MS_PER];
+    u32 sum = 0;
+#pragma unroll
+    for (u32 i = 0; i < MS_PER; ++i) {
+        const u32 c = tid * per + i;
+        h[i] = (i < per && c < chunks) ? hist[(size_t)c * MS_MAXB + b] : 0u;
+        sum += h[i];
+    }
+    u32 inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    u32 run = inc - sum, total = 0;
+    for (u32 w = 0; w < 4; ++w) { if (w < wv) run += s_w[w]; total += s_w[w]; }
+#pragma unroll
+    for (u32 i = 0; i < MS_PER; ++i) {
+        const u32 c = tid * per + i;
+        if (i < per && c < chunks) hist[(size_t)c * MS_MAXB + b] = run;
+        run += h[i];
+    }
+    if (tid == 0) {
+        tot[b] = total;
+        __threadfence();
+        s_last = atomicAdd(reinterpret_cast<u32*>(scal + 15), 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    __shared__ u32 s_t[MS_MAXB];
+    s_t[tid] = tid < nb ? __hip_atomic_load(&tot[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;   // (one round trip, not one per block)
+    __syncthreads();
+    if (tid != 0) return;
+    u32 raw = 0, pos = 0;
+    for (u32 bb = 0; bb < nb; ++bb) {
+        const u32 t = s_t[bb];
+        blk_raw[bb] = raw;
+        blk_pos[bb] = pos;
+        pos = ((pos + t + 3u) & ~3u) + WIN;
+        raw += t;
+    }
+    blk_raw[nb] = raw;
+    blk_pos[nb] = pos;
+    scal[3] = pos;
+}
+template <bool W>
+__global__ __launch_bounds__(MS_THREADS) void k_ms_place(const u32* __restrict__ rec_blk, const u64* __restrict__ rec_val,
+                                                          const u64* __restrict__ scal, const u32* __restrict__ base,
+                                                          const u32* __restrict__ blk_pos, const u32 nb, const u32* __restrict__ wkey,
+                                                          u32* __restrict__ brk, u32* __restrict__ info, u32* __restrict__ bw) {
+    constexpr u32 NWV = MS_THREADS / 64;
+    __shared__ u32 s_cnt[MS_ROUNDS * NWV][MS_MAXB];   // records of block b in (round, wave) slot; then: records before the slot
+    __shared__ u32 s_dst[MS_MAXB];                    // first place of this chunk's records of block b in the padded list
+    const u32 n = (u32)scal[1];
+    const u32 g0 = blockIdx.x * MS_CHUNK;
+    if (g0 >= n) return;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (u32 i = tid; i < MS_ROUNDS * NWV * MS_MAXB; i += MS_THREADS) (&s_cnt[0][0])[i] = 0;
+    s_dst[tid] = (tid < nb ? blk_pos[tid] : 0u) + base[(size_t)blockIdx.x * MS_MAXB + tid];
+    u32 blk[MS_ROUNDS], rk[MS_ROUNDS];
+    u64 val[MS_ROUNDS];
+#pragma unroll
+    for (u32 k = 0; k < MS_ROUNDS; ++k) {
+        const u32 g = g0 + k * MS_THREADS + tid;
+        blk[k] = g < n ? (rec_blk[g] & (MS_MAXB - 1)) : ~0u;
+        val[k] = g < n ? rec_val[g] : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < MS_ROUNDS; ++k) {
+        // lanes of this wave with the same block: eight ballots
+        unsigned long long m = __ballot(blk[k] != ~0u);
+#pragma unroll
+        for (u32 bit = 0; bit < 8; ++bit) {
+            const unsigned long long bal = __ballot((blk[k] >> bit) & 1u);
+            m &= ((blk[k] >> bit) & 1u) ? bal : ~bal;
+        }
+        const unsigned long long below = m & ((1ull << lane) - 1ull);
+        rk[k] = (u32)__popcll(below);
+        if (blk[k] != ~0u && below == 0) s_cnt[k * NWV + wv][blk[k]] = (u32)__popcll(m);   // (the first lane of every block present)
+    }
+    __syncthreads();
+    {   // per block: records in the slots before each (round, wave) slot
+        u32 run = 0;
+        for (u32 sl = 0; sl < MS_ROUNDS * NWV; ++sl) {
+            const u32 c = s_cnt[sl][tid];
+            s_cnt[sl][tid] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < MS_ROUNDS; ++k) {
+        if (blk[k] == ~0u) continue;
+        const u32 dst = s_dst[blk[k]] + s_cnt[k * NWV + wv][blk[k]] + rk[k];
+        brk[dst] = (u32)(val[k] >> 32);
+        info[dst] = (u32)val[k];
+        if (W) bw[dst] = wkey[(u32)(val[k] >> 32)];
+    }
+}
+
 // 1 when entry e opens a new (block, rank) group; evaluated on the fly by the scan and the passes after it
 // (two neighbouring loads of two arrays) instead of being written out by a pass of its own
 template <class V>

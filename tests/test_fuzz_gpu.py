@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 MODES = [{}, {"KSP_REORDER": "0"}, {"KSP_NO_SCHED": "1"}, {"KSP_COLLECT": "1"}, {"KSP_COLLECT": "0"},
          {"KSP_JOIN": "window"}, {"KSP_TAG32": "1"}, {"KSP_HASH_GROUP": "0"}, {"KSP_KEY_GROUPS": "0"},
          {"KSP_KEY_GROUPS": "0", "KSP_REORDER": "0"}, {"KSP_PART_MIN": "1"}, {"KSP_PARTITION": "rocprim"}, {"KSP_JOIN": "matches"}, {"KSP_JOIN": "matches", "KSP_COLLECT": "0"},
-         {"KSP_JOIN": "matches", "KSP_COLLECT": "1", "KSP_REORDER": "0"}, {"KSP_ALIGN": "0"}, {"KSP_ALIGN": "0", "KSP_KEY_GROUPS": "0"}, {"KSP_PART_MIN": "1", "KSP_SEG": "1"}, {"KSP_PART_MIN": "1", "KSP_SEG": "0"}]
+         {"KSP_JOIN": "matches", "KSP_COLLECT": "1", "KSP_REORDER": "0"}, {"KSP_ALIGN": "0"}, {"KSP_ALIGN": "0", "KSP_KEY_GROUPS": "0"}, {"KSP_PART_MIN": "1", "KSP_SEG": "1"}, {"KSP_PART_MIN": "1", "KSP_SEG": "0"}, {"KSP_MS": "0"}, {"KSP_MS": "0", "KSP_REORDER": "0"}]
 
 
 def _random_sketches(rng):
@@ -39,7 +39,7 @@ def test_random_sketches_all_modes(oracle_lib, seed, monkeypatch):
         ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
         for env in MODES:
             for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_JOIN", "KSP_TAG32", "KSP_HASH_GROUP", "KSP_KEY_GROUPS",
-                      "KSP_PART_MIN", "KSP_PARTITION", "KSP_ALIGN", "KSP_SEG"):
+                      "KSP_PART_MIN", "KSP_PARTITION", "KSP_ALIGN", "KSP_SEG", "KSP_MS"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
