@@ -141,6 +141,8 @@ struct ksp_engine {
     bool have_rank_pairs = false; // gp holds (block, rank) of every list word in rank order (key-by-key build)
     bool have_dwork = false;      // ... and dwork the diagonal work / holder sums (k_move_groups)
     ksp::Buf gp, gm, ms_hist;     // group records of the key-by-key build; parked masks; per-chunk block counts of the split (k_ms_*)
+    ksp::Buf pmask;               // the membership mask of every list word at its list position (written by k_ms_place)
+    bool pmask_on = false;        // ... of the lists the engine holds
     bool scal_fresh = false;      // h_scal[1 .. 11] hold the finished build's values (read back before its last kernels were queued)
     u64 gp_stride = 0;            // gp: gp_stride record values (u64), then as many blocks, ranks and sorted blocks (u32)
     bool reorder = true;          // order the sources by shared-key label before cutting blocks (KSP_REORDER=0: off)
@@ -892,8 +894,15 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                 hipLaunchKernelGGL(k_ms_scan, dim3(nb), dim3(256), 0, st, e->ms_hist.as<u32>(), scal, e->ms_hist.as<u32>() + (size_t)chunks_cap * MS_MAXB, blk_raw,
                                    blk_pos, nb);
                 hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
+                uint4* pm = nullptr;
+                if (!W) {   // unweighted lists: the join's bit-sliced paths read the masks at the list positions
+                    if ((rc = e->pmask.ensure((Kcap + (u64)nb * (WIN + 4) + 4 * WIN) * 16))) return rc;
+                    pm = e->pmask.as<uint4>();
+                }
                 hipLaunchKernelGGL((k_ms_place<W>), dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, rec_val, scal, e->ms_hist.as<u32>(),
-                                   blk_pos, nb, wkey, e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr);
+                                   blk_pos, nb, wkey, e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr,
+                                   e->mm.as<uint4>(), pm);
+                e->pmask_on = pm != nullptr;
             } else {
             tb = 0;   // (temporary storage for the bound, not for this build's K: K moves a little from build to build — the labels'
                           //  atomics race — and a buffer that has to grow in the middle of a build costs a device-wide stall)
@@ -1134,7 +1143,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
-                        &e->d_wg, &e->gp, &e->gm, &e->ms_hist, &e->PK, &e->PT, &e->PD, &e->parena, &e->PK2, &e->PT2, &e->PD2, &e->seg_tbl, &e->seg_grp, &e->seg_chk, &e->biglist, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
+                        &e->d_wg, &e->gp, &e->gm, &e->ms_hist, &e->pmask, &e->PK, &e->PT, &e->PD, &e->parena, &e->PK2, &e->PT2, &e->PD2, &e->seg_tbl, &e->seg_grp, &e->seg_chk, &e->biglist, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
                         &e->mr0, &e->mr1, &e->mstart};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);
@@ -1357,7 +1366,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     KSP_HIP(hipSetDevice(e->device));
     e->built = false;
     e->slice_ready = false;
-    e->sched_on = false; e->collect = false; e->have_bits = false; e->matches_on = false;   // (nothing of the previous build's work list survives)
+    e->sched_on = false; e->collect = false; e->have_bits = false; e->matches_on = false; e->pmask_on = false;   // (nothing of the previous build's work list survives)
     e->act_tid.clear(); e->act_rec.clear();
     for (u32 s = 0; s < n_sources; ++s)
         if (h_offsets[s + 1] < h_offsets[s]) { set_error("build: offsets not monotone"); return KSP_E_ARG; }
@@ -1465,7 +1474,7 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
     KSP_HIP(hipSetDevice(e->device));
     e->built = false;
     e->slice_ready = false;
-    e->sched_on = false; e->collect = false; e->have_bits = false; e->matches_on = false;
+    e->sched_on = false; e->collect = false; e->have_bits = false; e->matches_on = false; e->pmask_on = false;
     e->act_tid.clear(); e->act_rec.clear();
     e->ph_n = 0;
     e->slice_phase = 0;
@@ -1661,6 +1670,7 @@ int ksp_engine_assemble(ksp_engine* e, uint32_t nparts, const uint64_t* h_sizes 
     hipStream_t st = (hipStream_t)stream;
     KSP_HIP(hipSetDevice(e->device));
     e->built = false;
+    e->pmask_on = false;   // (the assembled lists have no positional masks)
     if (e->n_entries == 0 || e->nb == 0) { e->built = true; return KSP_OK; }
     const u32 nb = e->nb;
     u64 ktot = 0, utot = 0, bigtot = 0;
@@ -1808,6 +1818,7 @@ int ksp_engine_join_launch(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end
     a.info = e->info.as<u32>();
     a.bw = e->weighted ? e->bw.as<u32>() : nullptr;
     a.bigmask = e->mm.as<uint4>();
+    a.pmask = e->pmask_on ? e->pmask.as<uint4>() : nullptr;
     a.blk_raw = e->blk_raw.as<u32>();
     a.blk_pos = e->blk_pos.as<u32>();
     a.cidx = e->part.as<u32>();

@@ -11,6 +11,8 @@ struct JoinArgs {
     const u32* info;
     const u32* bw;      // NULL -> weight 1
     const uint4* bigmask; // 128-bit membership masks of the postings with > 4 sources
+    const uint4* pmask;   // (or NULL) the membership mask of EVERY list word at its list position: the bit-sliced paths read
+                          // it in place — one coalesced load instead of posting word -> mask index -> mask
     const u32* blk_raw; // nb + 1: unpadded distinct-key offsets (counts)
     const u32* blk_pos; // nb + 1: start of every block list in the padded layout
     const u32* cidx;    // nb * (ncell + 1): fine cell index, positions in the padded layout
@@ -609,31 +611,49 @@ __device__ inline void self_tile_popc(const JoinArgs& a, unsigned char* smem, co
     for (int i = 0; i < 16; ++i) acc[i] = 0;
     u32 dacc = 0;
     WGT_ACC(a, 4);
+    // the posting words of a chunk are requested while the previous chunk is being accumulated (they are the first
+    // of two dependent loads: posting word -> mask), so a chunk starts with its mask loads
+    constexpr u32 GW = (G + JW - 1) / JW, GB = 3;   // groups per wave and chunk, in batches of GB (register budget)
+    u32 inf_n[GW];
+    auto fetch_inf = [&](const u32 base) {
+#pragma unroll
+        for (u32 q = 0; q < GW; ++q) {
+            const u32 g = (u32)wv + q * JW, k = base + 64u * g + (u32)lane;
+            inf_n[q] = (base < klen && g < G && k < klen) ? a.info[kb0 + k] : 0xFFFFFFFFu;
+        }
+    };
+    if (!a.pmask) fetch_inf(0);
+    else {
+#pragma unroll
+        for (u32 q = 0; q < GW; ++q) inf_n[q] = 0xFFFFFFFFu;
+    }
     for (u32 base = 0; base < klen; base += G * 64) {
         const u32 ng = min(G, (klen - base + 63u) / 64u);
-        // transpose 64 masks into 128 column words; a wave takes groups wv, wv + JW, ...  All posting
-        // words, then all masks of the wave's groups are requested before the first is used (two
-        // rounds of memory latency per chunk, not two per group)
-        constexpr u32 GW = (G + JW - 1) / JW, GB = 3;   // groups per wave and chunk, in batches of GB (register budget)
+        // transpose 64 masks into 128 column words; a wave takes groups wv, wv + JW, ...
+        u32 inf_c[GW];
+#pragma unroll
+        for (u32 q = 0; q < GW; ++q) inf_c[q] = inf_n[q];
         for (u32 q0 = 0; q0 < GW; q0 += GB) {
-            u32 inf[GB];
             uint4 mk[GB];
 #pragma unroll
             for (u32 q = 0; q < GB; ++q) {
-                const u32 g = (u32)wv + (q0 + q) * JW, k = base + 64u * g + (u32)lane;
-                inf[q] = (g < ng && k < klen) ? a.info[kb0 + k] : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (u32 q = 0; q < GB; ++q) {
                 mk[q] = make_uint4(0, 0, 0, 0);
-                if (inf[q] != 0xFFFFFFFFu && inf[q] >= BIG) mk[q] = a.bigmask[inf[q] & ~BIG];
+                if (a.pmask) {   // masks at their list positions: one coalesced load, no posting word needed
+                    const u32 g = (u32)wv + (q0 + q) * JW, k = base + 64u * g + (u32)lane;
+                    if (q0 + q < GW && g < ng && k < klen) mk[q] = a.pmask[kb0 + k];
+                } else {
+                    const u32 inf = q0 + q < GW ? inf_c[q0 + q] : 0xFFFFFFFFu;
+                    if (inf != 0xFFFFFFFFu && inf >= BIG) mk[q] = a.bigmask[inf & ~BIG];
+                }
             }
+            if (q0 == 0 && !a.pmask) fetch_inf(base + G * 64);   // (the next chunk's posting words: in flight during this chunk's work)
 #pragma unroll
             for (u32 q = 0; q < GB; ++q) {
                 const u32 g = (u32)wv + (q0 + q) * JW;
-                if (g < ng) {
+                if (q0 + q < GW && g < ng) {
+                    const u32 inf = inf_c[q0 + q];
                     uint4 m = mk[q];
-                    if (inf[q] != 0xFFFFFFFFu && inf[q] < BIG) m = posting_mask(inf[q], a.bigmask);   // inline ids -> mask
+                    if (!a.pmask && inf != 0xFFFFFFFFu && inf < BIG) m = posting_mask(inf, a.bigmask);   // inline ids -> mask
                     const u64 lo = transpose64((u64)m.x | ((u64)m.y << 32), lane);
                     const u64 hi = transpose64((u64)m.z | ((u64)m.w << 32), lane);
                     col[g * 128u + (u32)lane] = lo;
@@ -734,6 +754,10 @@ __device__ inline void join_cells_collect(const JoinArgs& a, unsigned char* smem
         }
     };
     open_cell();
+    // the keys of the wave's NEXT step are requested as soon as the step is known (end of the previous one): they
+    // arrive while the workgroup collects and accumulates — a round was two memory round trips before its search began
+    uint4 An = make_uint4(INF_A, INF_A, INF_A, INF_A), Bn = make_uint4(PAD, PAD, PAD, PAD);
+    if (have) { An = load_a(a, ca, a0, a1, lane); Bn = load_b(a, cb, b1, lane); }
     // the two 4 x 4 patches of this thread: rows 4 pi .. (block I), columns 4 pj .. (block J)
     const u32 pi0 = (u32)tid >> 5, pi1 = pi0 + 16u, pj = (u32)tid & 31u;
     constexpr int NA = C16 ? 8 : 16;   // C16: acc[k] = pairs (x, 2k) and (x, 2k + 1) ... see below
@@ -748,8 +772,7 @@ __device__ inline void join_cells_collect(const JoinArgs& a, unsigned char* smem
         __syncthreads();
         if (have) {
             // one step: chunk [ca, ca + 256) of the cell's A keys against window [cb, cb + 256) of its B keys
-            const uint4 A = load_a(a, ca, a0, a1, lane);
-            const uint4 B = load_b(a, cb, b1, lane);
+            const uint4 A = An, B = Bn;
             Window& wn = wl.win;
             u32* l2w = reinterpret_cast<u32*>(wn.l2);
             u32* l1w = reinterpret_cast<u32*>(wn.l1);
@@ -787,6 +810,7 @@ __device__ inline void join_cells_collect(const JoinArgs& a, unsigned char* smem
                 cb += WIN;
                 if (cb >= b1) { c += JW; open_cell(); }
             }
+            if (have) { An = load_a(a, ca, a0, a1, lane); Bn = load_b(a, cb, b1, lane); }
             if (have && lane == 0) s_more = 1;
         }
         WGT_ACC(a, 5);
@@ -800,9 +824,14 @@ __device__ inline void join_cells_collect(const JoinArgs& a, unsigned char* smem
             uint4 ma = make_uint4(0, 0, 0, 0), mbm = ma;
             if (mi < n) {
                 const uint2 q = cl.match[mi];
-                const u32 ia = a.info[q.x], ib = a.info[q.y];
-                ma = posting_mask(ia, a.bigmask);
-                mbm = posting_mask(ib, a.bigmask);
+                if (a.pmask) {   // masks at the list positions of the match: one round of memory latency
+                    ma = a.pmask[q.x];
+                    mbm = a.pmask[q.y];
+                } else {
+                    const u32 ia = a.info[q.x], ib = a.info[q.y];
+                    ma = posting_mask(ia, a.bigmask);
+                    mbm = posting_mask(ib, a.bigmask);
+                }
             }
             if (mb + 64u * (u32)wv < n) {   // wave-uniform; one transpose at a time keeps the register count down
                 cl.col[0][wv][lane] = transpose64((u64)ma.x | ((u64)ma.y << 32), lane);

@@ -1121,6 +1121,7 @@ __global__ void k_place_groups(const u32* __restrict__ sblk, const u64* __restri
 // chunk — equal blocks inside a wave by eight ballots, waves and rounds through a small LDS table — and writes ranks
 // and posting words straight into the padded lists.
 constexpr u32 MS_CHUNK = 2048, MS_THREADS = 256, MS_ROUNDS = MS_CHUNK / MS_THREADS, MS_MAXB = 256;
+constexpr u32 PM_BIG = 0xE0000000u;   // (= BIG: posting word with a mask index)
 __global__ __launch_bounds__(MS_THREADS) void k_ms_hist(const u32* __restrict__ rec_blk, u64* __restrict__ scal,
                                                          u32* __restrict__ hist) {
     __shared__ u32 s_h[MS_MAXB];
@@ -1196,7 +1197,8 @@ template <bool W>
 __global__ __launch_bounds__(MS_THREADS) void k_ms_place(const u32* __restrict__ rec_blk, const u64* __restrict__ rec_val,
                                                           const u64* __restrict__ scal, const u32* __restrict__ base,
                                                           const u32* __restrict__ blk_pos, const u32 nb, const u32* __restrict__ wkey,
-                                                          u32* __restrict__ brk, u32* __restrict__ info, u32* __restrict__ bw) {
+                                                          u32* __restrict__ brk, u32* __restrict__ info, u32* __restrict__ bw,
+                                                          const uint4* __restrict__ bigmask, uint4* __restrict__ pmask) {
     constexpr u32 NWV = MS_THREADS / 64;
     __shared__ u32 s_cnt[MS_ROUNDS * NWV][MS_MAXB];   // records of block b in (round, wave) slot; then: records before the slot
     __shared__ u32 s_dst[MS_MAXB];                    // first place of this chunk's records of block b in the padded list
@@ -1245,6 +1247,22 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_place(const u32* __restrict__
         brk[dst] = (u32)(val[k] >> 32);
         info[dst] = (u32)val[k];
         if (W) bw[dst] = wkey[(u32)(val[k] >> 32)];
+        if (pmask) {   // the word's membership mask at its list position (inline ids expanded): the join reads it in place
+            const u32 inf = (u32)val[k];
+            uint4 m;
+            if (inf >= PM_BIG) m = bigmask[inf & ~PM_BIG];
+            else {
+                u32 w4[4] = {0, 0, 0, 0};
+                const u32 cnt = (inf >> 29) + 1;
+                for (u32 x = 0; x < cnt; ++x) {
+                    const u32 id = (inf >> (7 * x)) & 127u;
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) w4[z] |= (id >> 5) == (u32)z ? (1u << (id & 31)) : 0u;
+                }
+                m = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+            pmask[dst] = m;
+        }
     }
 }
 

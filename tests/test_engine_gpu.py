@@ -390,3 +390,33 @@ def test_postings_rejects_bad_source_index():
     assert ei.value.code == engine.KSP_E_ARG
     with pytest.raises(engine.KspError):
         e.build_postings(np.array([0, 1, 4], dtype=np.uint64), dsrc.ptr.value, 0, 8)   # a key with one holder
+
+
+def test_join_in_two_halves_with_the_next_build_queued_behind_it(oracle_lib):
+    """ksp_engine_join_launch / _wait (what bench.py pipelines): the join of set A is launched, the build of set B is
+    queued on the same stream behind it, and only then is A's count collected — A's edges are A's (the build of B
+    overwrites the engine's lists only after the join has run), B's join after that is B's."""
+    if os.environ.get("KSP_NO_SCHED"):
+        pytest.skip("one ordering is enough")
+    a = synth.generate("C2", n_sources=700, mean_size=500, cluster_cap=50, seed=611)
+    b = synth.generate("C2", n_sources=450, mean_size=800, cluster_cap=30, seed=612)
+    ref_a, ref_b = oracle_lib.brute_pairs(a.keys, a.offsets), oracle_lib.brute_pairs(b.keys, b.offsets)
+    da, db = engine.DeviceBuffer.from_numpy(a.keys), engine.DeviceBuffer.from_numpy(b.keys)
+    e = engine.Engine(0)
+    cap = 1 << 20
+    out_a, out_b = engine.DeviceBuffer(cap * 16), engine.DeviceBuffer(cap * 16)
+    for _ in range(3):
+        e.build_blocks(da.ptr.value, a.offsets)
+        e.join_launch(0, e.num_tiles, out_a.ptr.value, cap)
+        e.build_blocks(db.ptr.value, b.offsets)          # queued behind the launched join
+        cnt_a = e.join_wait()
+        e.join_launch(0, e.num_tiles, out_b.ptr.value, cap)
+        cnt_b = e.join_wait()
+        assert e.join_wait() == 0                        # nothing pending: no count
+        got_a = np.sort(out_a.to_numpy(engine.EDGE_DTYPE, cnt_a), order=["source_1", "source_2"])
+        got_b = np.sort(out_b.to_numpy(engine.EDGE_DTYPE, cnt_b), order=["source_1", "source_2"])
+        assert len(got_a) == len(ref_a) and (got_a == ref_a).all()
+        assert len(got_b) == len(ref_b) and (got_b == ref_b).all()
+    for x in (out_a, out_b, da, db):
+        x.free()
+    e.close()

@@ -27,15 +27,16 @@ GROUPS = [  # (substring of the kernel name, group)
     ("k_max_last", "key range + source sizes"), ("k_src_size", "key range + source sizes"), ("k_iota4", "key range + source sizes"),
     ("k_tag", "tags + source sizes"),
     ("k_zero_regions", "key range + source sizes"),
-    ("k_part", "partition"), ("k_hist2", "partition"), ("k_scan2", "partition"), ("k_scatter2", "partition"),
+    ("k_seg_", "partition"), ("k_part", "partition"), ("k_hist2", "partition"), ("k_scan2", "partition"), ("k_scatter2", "partition"),
     ("radix_sort_onesweep", "partition"), ("onesweep_histograms", "partition"),
     ("k_match", "match records"),
     ("k_bucket", "bucket grouping"),
     ("k_label", "source labels + order"), ("k_perm", "source labels + order"), ("k_blk_bound", "source labels + order"),
+    ("k_pack_blocks", "source labels + order"), ("k_place_sources", "source labels + order"),
     ("k_key_groups", "key groups"), ("k_group_totals", "key groups"),
     ("k_move_groups", "block lists"), ("k_blk_raw", "block lists"), ("k_blk_pos", "block lists"), ("k_pad", "block lists"),
-    ("k_place_groups", "block lists"), ("k_cidx", "block lists"),
-    ("k_tile_flags", "work list"), ("k_pack_flags", "work list"), ("k_list_pairs", "work list"),
+    ("k_place_groups", "block lists"), ("k_cidx", "block lists"), ("k_ms_", "block lists"),
+    ("k_tile_flags", "work list"), ("k_pack_flags", "work list"), ("k_list_pairs", "work list"), ("k_copy_regions", "work list"),
     ("k_join", "join"),
 ]
 
