@@ -1196,10 +1196,12 @@ static int build_schedule(ksp_engine* e) {
     int rc;
     if ((rc = query_slots(e))) return rc;
     auto words_of = [&](u32 b) { return (u64)(e->h_blk_off[b + 1] - e->h_blk_off[b]); };
+    u64 diag_cost = 40;
+    if (const char* dc = std::getenv("KSP_DEBUG_DIAGCOST")) diag_cost = (u64)std::max(1, std::atoi(dc));   // (timing experiments)
     u64 off_cost = 24;   // (8 — the search alone — left the off-diagonal shares of C2 at twice the time of the diagonal ones: join 0.283 -> 0.246 ms)
     if (const char* oc = std::getenv("KSP_DEBUG_OFFCOST")) off_cost = (u64)std::max(1, std::atoi(oc));   // (timing experiments)
     auto cost_of = [&](u32 I, u32 J) -> u64 {
-        if (I == J && !e->weighted) return 40 * words_of(I) + 20000;   // bit-sliced: 16 popcounts x 528 patches per 64 keys
+        if (I == J && !e->weighted) return diag_cost * words_of(I) + 20000;   // bit-sliced: 16 popcounts x 528 patches per 64 keys
         return I == J ? dw[I] / 2 + 10 * words_of(I) + 20000 : off_cost * (words_of(I) + words_of(J)) + 20000;
     };
     // pass 1: active tiles
