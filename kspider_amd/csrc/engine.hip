@@ -400,20 +400,22 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     const bool hand = nb_hand > 0;
     // the segment partition (k_seg_bounds / k_seg_scatter): two levels, runs long enough to leave a dozen entries per
     // (source, range) and no run so long that the one wave that streams it would be the launch
-    bool seg = false;
+    bool seg = false, seg3_used = false;
     u32 seg_cap = 0, seg_nb1 = 0;
+    // (one source's segment must fit a tile: a run so long that its share of one range would not is a build for the
+    //  paged levels — known before anything is launched, instead of finding out from the overflow word)
+    auto seg_runs_fit = [&](const u32 r1) {
+        u64 longest = 0;
+        for (u32 s_ = 0; s_ < N; ++s_) longest = std::max(longest, e->h_off[s_ + 1] - e->h_off[s_]);
+        return longest / std::max<u32>(1, r1) <= SEG_FILL;
+    };
     int seg_pb2 = 0;
     if (hand && nb_hand <= 65536 && !e->seg_off && e->h_off.size() == (size_t)N + 1 && N) {
         const char* sv = std::getenv("KSP_SEG");   // 0: never, 1: whatever the segment length (diagnostic / tests)
         while (((nb_hand + (1u << seg_pb2) - 1) >> seg_pb2) > 256) ++seg_pb2;
         seg_nb1 = (nb_hand + (1u << seg_pb2) - 1) >> seg_pb2;
         const u64 mean_seg = n / N / seg_nb1;
-        seg = (sv ? std::atoi(sv) != 0 : mean_seg >= SEG_MIN_LEN);
-        if (seg) {
-            u64 longest = 0;
-            for (u32 s_ = 0; s_ < N; ++s_) longest = std::max(longest, e->h_off[s_ + 1] - e->h_off[s_]);
-            if (longest > 64 * std::max<u64>(1, n / N) + 65536) seg = false;
-        }
+        seg = (sv ? std::atoi(sv) != 0 : mean_seg >= SEG_MIN_LEN && seg_runs_fit(seg_nb1));
         if (seg) {
             const u64 mean = n / nb_hand + 1;
             seg_cap = (u32)((mean + mean / 2 + 128 + 63) & ~63ull);   // (a multiple of 64 places: every bucket starts on a memory line)
@@ -602,17 +604,16 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         u64* bbase = bsum + nbuckets;
         u32* bstart = (u32*)(bbase + nbuckets);   // nbuckets + 1
         u32* d_hovf = (u32*)(scal + 9);
-        BucketBounds bb{bstart, nullptr, 0u};
-        if (seg) {
-            // level 1 is already in the sketches (sorted runs): boundaries of every source's segments, then the scatter
-            // gathers its tiles from the segments; fixed places per bucket, the cursors count what arrived
-            const size_t tbl_words = (size_t)N * (seg_nb1 + 1);
+        // tables of the segment partition for `r1` ranges: boundary table, source groups and 2 048-entry chunks (host side,
+        // rebuilt when the offsets or the range count change)
+        auto seg_tables = [&](const u32 r1) -> int {
+            const size_t tbl_words = (size_t)N * (r1 + 1);
             if ((rc = e->seg_tbl.ensure(tbl_words * 4))) return rc;
-            if (!e->seg_groups_ok || e->seg_groups_nb1 != seg_nb1) {
+            if (!e->seg_groups_ok || e->seg_groups_nb1 != r1) {
                 std::vector<u32>& gs = e->seg_groups;
                 gs.clear();
                 gs.push_back(0);
-                const u64 per = (u64)SEG_FILL * seg_nb1;
+                const u64 per = (u64)SEG_FILL * r1;
                 u64 acc = 0;
                 u32 cnt_s = 0;
                 for (u32 s_ = 0; s_ < N; ++s_) {
@@ -635,11 +636,18 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                 }
                 if ((rc = e->seg_chk.ensure(ck.size() * 16))) return rc;
                 KSP_HIP(hipMemcpyAsync(e->seg_chk.p, ck.data(), ck.size() * 16, hipMemcpyHostToDevice, st));
-                e->seg_groups_nb1 = seg_nb1;
+                e->seg_groups_nb1 = r1;
                 e->seg_groups_ok = true;
                 if ((rc = e->seg_grp.ensure(gs.size() * 4 + 16 + 258 * 8))) return rc;   // (+ the ranges' first keys, k_seg_prep)
                 KSP_HIP(hipMemcpyAsync(e->seg_grp.p, gs.data(), gs.size() * 4, hipMemcpyHostToDevice, st));
             }
+            return KSP_OK;
+        };
+        BucketBounds bb{bstart, nullptr, 0u};
+        if (seg) {
+            // level 1 is already in the sketches (sorted runs): boundaries of every source's segments, then the scatter
+            // gathers its tiles from the segments; fixed places per bucket, the cursors count what arrived
+            if ((rc = seg_tables(seg_nb1))) return rc;
             const u32 ngroups_s = (u32)e->seg_groups.size() - 1;
             phase_mark(e, st, "partition");
             KSP_HIP(hipEventRecord(e->ev[4], st));
@@ -654,9 +662,19 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             bb = BucketBounds{nullptr, hp_gcnt, seg_cap};
         } else if (hand) {
             // partition by bucket = floor(key * nbuckets / (max key + 1)): d_keys -> level-1 pages [-> middle pages] -> KA, VB, bstart
-            if ((rc = e->PK.ensure(hp_pages_a * P1_PAGE * 8))) return rc;
-            if ((rc = e->PT.ensure(hp_pages_a * P1_PAGE * sizeof(V)))) return rc;
-            if ((rc = e->PD.ensure(hp_pages_a * P1_PAGE))) return rc;
+            // three levels: level 1 can be read off the sorted runs too (k_seg_mid), for runs that leave a dozen entries per
+            // (source, level-1 bucket)
+            bool seg3 = false;
+            if (hp_pbm && !e->seg_off && e->h_off.size() == (size_t)N + 1 && N) {
+                const char* sv = std::getenv("KSP_SEG");
+                seg3 = sv ? std::atoi(sv) != 0 : n / N / hp_nb1 >= SEG_MIN_LEN && seg_runs_fit(hp_nb1);
+            }
+            seg3_used = seg3;
+            if (!seg3) {
+                if ((rc = e->PK.ensure(hp_pages_a * P1_PAGE * 8))) return rc;
+                if ((rc = e->PT.ensure(hp_pages_a * P1_PAGE * sizeof(V)))) return rc;
+                if ((rc = e->PD.ensure(hp_pages_a * P1_PAGE))) return rc;
+            } else if ((rc = seg_tables(hp_nb1))) return rc;
             if (hp_pbm) {
                 if ((rc = e->PK2.ensure(hp_pages_m * P1_PAGE * 8))) return rc;
                 if ((rc = e->PT2.ensure(hp_pages_m * P1_PAGE * sizeof(V)))) return rc;
@@ -664,11 +682,21 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             }
             phase_mark(e, st, "partition");
             KSP_HIP(hipEventRecord(e->ev[4], st));
+            if (seg3) {
+                u64* kmin = (u64*)((char*)e->seg_grp.p + (((e->seg_groups.size() * 4) + 15) & ~(size_t)15));
+                hipLaunchKernelGGL(k_seg_prep, dim3(1), dim3(256), 0, st, scal, nbuckets, hp_pb2 + hp_pbm, hp_nb1, kmin);
+                hipLaunchKernelGGL(k_seg_bounds, dim3((u32)e->seg_chunks.size()), dim3(64 * SEG_BW), 0, st, d_keys, e->seg_chk.as<uint4>(), scal, kmin,
+                                   hp_pb2 + hp_pbm, nbuckets - 1, hp_nb1, e->seg_tbl.as<u32>());
+                hipLaunchKernelGGL((k_seg_mid<V>), dim3(((u32)e->seg_groups.size() - 1) * hp_nb1), dim3(P2_THREADS), 0, st, d_keys, d_off,
+                                   e->seg_tbl.as<u32>(), e->seg_grp.as<u32>(), scal, hp_pb2, hp_pbm, nbuckets - 1, hp_nb1, hp_m, e->PK2.as<u64>(),
+                                   e->PT2.as<V>(), e->PD2.as<u8>());
+            } else {
             hipLaunchKernelGGL(k_part_src, dim3(grid_for((u64)hp_nchunks + 1, bs)), dim3(bs), 0, st, d_off, N, hp_nchunks, hp_src, scal,
                                nbuckets);
             hipLaunchKernelGGL((k_part1<V>), dim3(hp_nchunks), dim3(P1_THREADS), 0, st, d_keys, d_off, N, (u32)nw, scal,
                                hp_pb2 + hp_pbm, hp_pb2, nbuckets - 1, hp_a, hp_src, e->PK.as<u64>(), e->PT.as<V>(), e->PD.as<u8>());
-            if (hp_pbm)
+            }
+            if (hp_pbm && !seg3)
                 hipLaunchKernelGGL((k_part_mid<V>), dim3((u32)hp_pages_a), dim3(P2_THREADS), 0, st, scal, hp_a, hp_m, hp_pb2, hp_pbm,
                                    nbuckets - 1, e->PK.as<u64>(), e->PT.as<V>(), e->PD.as<u8>(), e->PK2.as<u64>(), e->PT2.as<V>(),
                                    e->PD2.as<u8>());
@@ -699,7 +727,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         }
         e->sort_entries = nw;
         e->sort_bits = pb;
-        e->part_kind = seg ? 3 : hand ? 2 : 1;
+        e->part_kind = (seg || seg3_used) ? 3 : hand ? 2 : 1;
         if (!e->hb_slots) {   // persistent workgroups: as many as fit on the device at once
             int per_cu = 0, cus = 0;
             KSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bucket_group, HB_THREADS, 0));
@@ -736,7 +764,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             KSP_HIP(hipStreamSynchronize(st));
         }
         if (hand) {
-            if (seg && (u32)e->h_scal[PC_OVF]) {   // a tile or a bucket of the segment partition overflowed: the paged levels from now on
+            if ((seg || seg3_used) && ((u32)e->h_scal[PC_OVF] == 4 || (u32)e->h_scal[PC_OVF] == 5)) {   // a tile or a bucket of the segment partition overflowed: the paged levels from now on
                 e->seg_off = true;
                 e->part_fail = (int)(u32)e->h_scal[PC_OVF];
                 return build_impl<V>(e, d_keys, d_w, st, phase);

@@ -719,3 +719,120 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
         }
     }
 }
+
+// Sets of more than 65 536 buckets (three levels): the same trick for THEIR level 1 — one workgroup per (group of
+// sources, level-1 bucket) gathers its tile from the segments of the sorted runs and then is k_part_mid: the tile is
+// ordered by the middle digit in LDS, every digit present reserves its run in the paged list of its (level-1 bucket,
+// middle digit) and keys, tags and the final level's digit bytes are written out.  k_part1's copy of every entry
+// (8 bytes read, 11 written, 11 read again by k_part_mid) becomes one boundary pass (8 read) and a gather.
+template <class V>
+__global__ __launch_bounds__(P2_THREADS) void k_seg_mid(const u64* __restrict__ keys, const u64* __restrict__ off,
+                                                        const u32* __restrict__ bnd, const u32* __restrict__ groups,
+                                                        u64* __restrict__ scal, const int pb2, const int pbm, const u32 nbm1,
+                                                        const u32 nb1, const PartLists pm, u64* __restrict__ Km,
+                                                        V* __restrict__ Tm, u8* __restrict__ Dm) {
+    __shared__ u64 s_key[P2_TILE];
+    __shared__ V s_tag[P2_TILE];
+    __shared__ u8 s_dig[P2_TILE], s_bin[P2_TILE];
+    __shared__ u32 s_ls[256], s_cnt[256], s_v[256], s_g0[256], s_g1[256];
+    __shared__ u32 s_pre[SEG_SMAX + 1], s_addr[SEG_SMAX];
+    __shared__ u32 s_w[P2_THREADS / 64];
+    u32* const ovf = reinterpret_cast<u32*>(scal + PC_OVF);
+    if (*ovf) return;
+    const u32 g = blockIdx.x / nb1, BA = blockIdx.x % nb1;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 s0 = groups[g], ns = groups[g + 1] - s0;        // (<= SEG_SMAX by construction)
+    u32 len = 0;
+    if (tid < ns) {
+        const u32* row = bnd + (size_t)(s0 + tid) * (nb1 + 1) + BA;
+        const u32 lo = row[0], hi = row[1];
+        len = hi - lo;
+        s_addr[tid] = (u32)off[s0 + tid] + lo;
+    }
+    u32 inc = len;
+    for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+    if (lane == 63) s_w[wv] = inc;
+    if (tid < 256) s_cnt[tid] = 0;
+    __syncthreads();
+    u32 run = inc - len, m = 0;
+    for (u32 w = 0; w < P2_THREADS / 64; ++w) { if (w < wv) run += s_w[w]; m += s_w[w]; }
+    if (tid < ns) s_pre[tid] = run;
+    if (tid == 0) s_pre[ns] = m;
+    if (m > P2_TILE) {
+        if (tid == 0) __hip_atomic_store(ovf, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    __syncthreads();
+    const u32 nmid = 1u << pbm, sub = blockIdx.x & (pm.subs - 1);
+    const u64 mult = scal[PC_MULT];
+    const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
+    u64 key[P2_EPT];
+    V tag[P2_EPT];
+    u32 rk[P2_EPT], dig[P2_EPT];
+#pragma unroll
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        key[k] = 0; tag[k] = V(0);
+        if (i < m) {
+            u32 lo = 0, hi = ns;   // s_pre[lo] <= i < s_pre[hi]
+            while (hi - lo > 1) {
+                const u32 mid = (lo + hi) >> 1;
+                if (s_pre[mid] <= i) lo = mid; else hi = mid;
+            }
+            key[k] = __builtin_nontemporal_load(keys + s_addr[lo] + (i - s_pre[lo]));
+            const u32 src = s0 + lo;
+            tag[k] = make_tag<V>(((src / TB) << 8) | (src % TB), 0u);
+        }
+    }
+#pragma unroll
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        const u32 b = part_bucket(key[k], mult, ident, nbm1);
+        dig[k] = b & ((1u << pb2) - 1u);
+        rk[k] = (b >> pb2) & (nmid - 1);
+        if (i < m) rk[k] |= atomicAdd(&s_cnt[rk[k]], 1u) << 8;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        u32 c[4], t = 0;
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) { c[i] = s_cnt[4 * lane + i]; t += c[i]; }
+        u32 in2 = t;
+        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(in2, o); if ((int)lane >= o) in2 += up; }
+        u32 r2 = in2 - t;
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) { s_ls[4 * lane + i] = r2; r2 += c[i]; }
+    } else if (tid - 64 < 256) {   // one reservation per middle digit present in the tile
+        const u32 bin = tid - 64, c = s_cnt[bin];
+        u32 v = 0, g0 = ~0u, g1 = ~0u;
+        if (c) part_reserve(pm, ((BA << pbm) | bin) * pm.subs + sub, sub, c, ovf, v, g0, g1);
+        s_v[bin] = v; s_g0[bin] = g0; s_g1[bin] = g1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        if (i < m) {
+            const u32 bin = rk[k] & 0xFFu, slot = s_ls[bin] + (rk[k] >> 8);
+            s_key[slot] = key[k];
+            s_tag[slot] = tag[k];
+            s_dig[slot] = (u8)dig[k];
+            s_bin[slot] = (u8)bin;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < P2_EPT; ++k) {
+        const u32 i = k * P2_THREADS + tid;
+        if (i < m) {
+            const u32 bin = s_bin[i], base = s_v[bin], v = base + (i - s_ls[bin]);
+            const u32 ph = (v >> P1_PLOG) == (base >> P1_PLOG) ? s_g0[bin] : s_g1[bin];
+            if (ph != ~0u) {
+                const size_t a = ((size_t)ph << P1_PLOG) | (v & (P1_PAGE - 1));
+                Km[a] = s_key[i];
+                Tm[a] = s_tag[i];
+                Dm[a] = s_dig[i];
+            }
+        }
+    }
+}

@@ -137,10 +137,11 @@ def test_three_levels_when_there_are_more_than_65536_buckets(oracle_lib, monkeyp
     assert int(sk.offsets[-1]) > 1_200_000                      # / 16 per bucket: > 65 536 buckets
     ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
     for mean in ("16", "9"):
-        hand, st = _edges(sk, monkeypatch, KSP_PART_MIN="1", KSP_DEBUG_BUCKET_MEAN=mean)   # (more than 65 536 buckets: never the segment partition)
-        assert st["partition_kind"] == 2 and st["partition_fallback"] == 0, st
-        assert st["sort_bits"] > 16                                 # more than 2^16 buckets
-        assert len(hand) == len(ref) and (hand == ref).all()
+        for seg, kind in (("0", 2), ("1", 3)):   # level 1 copied into pages (k_part1) / read off the sorted runs (k_seg_mid)
+            hand, st = _edges(sk, monkeypatch, KSP_PART_MIN="1", KSP_DEBUG_BUCKET_MEAN=mean, KSP_SEG=seg)
+            assert st["partition_kind"] == kind and st["partition_fallback"] == 0, st
+            assert st["sort_bits"] > 16                                 # more than 2^16 buckets
+            assert len(hand) == len(ref) and (hand == ref).all()
 
 
 def test_segment_partition_shapes(oracle_lib, monkeypatch):
