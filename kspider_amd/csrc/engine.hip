@@ -141,6 +141,8 @@ struct ksp_engine {
     bool have_rank_pairs = false; // gp holds (block, rank) of every list word in rank order (key-by-key build)
     bool have_dwork = false;      // ... and dwork the diagonal work / holder sums (k_move_groups)
     ksp::Buf gp, gm, ms_hist;     // group records of the key-by-key build; parked masks; per-chunk block counts of the split (k_ms_*)
+    ksp::Buf crank;               // rank of every 4 096th kept entry (what the key-by-key list build reads instead of a rank per entry)
+    bool rank1_ok = false;        // R1 holds a rank per kept entry (sort path, postings input; the bucket grouping only writes crank)
     ksp::Buf pmask;               // the membership mask of every list word at its list position (written by k_ms_place)
     bool pmask_on = false;        // ... of the lists the engine holds
     bool scal_fresh = false;      // h_scal[1 .. 11] hold the finished build's values (read back before its last kernels were queued)
@@ -337,6 +339,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     u32* blk_pos = e->blk_pos.as<u32>();
     const unsigned bs = 256;
     u32* rank1 = e->R1.as<u32>();
+    if ((rc = e->crank.ensure((n / CR_CHUNK + 4) * 4))) return rc;
+    u32* crank = e->crank.as<u32>();
     const size_t NN = smap_stride(e);
     if ((rc = e->smap.ensure(7 * NN * 4))) return rc;
     // per-source maps: [0] label, [1] iota, [2] sorted labels, [3] order (= engine index -> source id; ~0: a hole),
@@ -373,6 +377,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         KSP_HIP(hipMemsetAsync(scal + 4, 0, 8, st));
         hipLaunchKernelGGL((k_post_expand<V, W>), dim3(grid_for(nk, bs)), dim3(bs), 0, st, e->post_off, e->post_src,
                            e->post_w, VA, rank1, sbound, nk, N, (u32*)(scal + 4));
+        hipLaunchKernelGGL(k_crank_from_rank, dim3(grid_for(m / CR_CHUNK + 1, bs)), dim3(bs), 0, st, rank1, crank, (u32)m);   // (postings: a rank per entry exists)
+        e->rank1_ok = true;
         {   // U = number of keys (what the prune scan reports on the sketch path)
             e->h_scal[2] = nk;
             KSP_HIP(hipMemcpyAsync(scal + 2, e->h_scal + 2, 8, hipMemcpyHostToDevice, st));
@@ -740,16 +746,19 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         u32* big_list = e->biglist.as<u32>();
         hipLaunchKernelGGL(k_bucket_group, dim3(std::min(nbuckets, e->hb_slots)), dim3(HB_THREADS), 0, st, KA, bb,
                            nbuckets, (u32)nw, rec, bsum, d_hovf, big_list);
+        // (a rank per kept entry only when the sort-by-block fallback is known to follow: the key-by-key build reads crank[])
+        u32* rank_out = e->key_groups_off ? rank1 : nullptr;
+        e->rank1_ok = rank_out != nullptr;
         hipLaunchKernelGGL((k_bucket_big<V, 0>), dim3(1024), dim3(HB_THREADS), 0, st, KA, VB, bb, big_list, d_hovf,
-                           bsum, (const u64*)nullptr, VA, rank1, first);
+                           bsum, (const u64*)nullptr, VA, rank_out, first, crank);
         size_t tb2 = 0;
         KSP_HIP(rocprim::exclusive_scan(nullptr, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
         if ((rc = e->tmp.ensure(tb2))) return rc;
         KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
         hipLaunchKernelGGL((k_bucket_emit<V>), dim3((nbuckets + HB_EMIT - 1) / HB_EMIT), dim3(HB_THREADS), 0, st, rec, VB, bb,
-                           bbase, bsum, nbuckets, VA, rank1, first, scal);
+                           bbase, bsum, nbuckets, VA, rank_out, first, scal, crank);
         hipLaunchKernelGGL((k_bucket_big<V, 1>), dim3(1024), dim3(HB_THREADS), 0, st, KA, VB, bb, big_list, d_hovf,
-                           bsum, bbase, VA, rank1, first);
+                           bsum, bbase, VA, rank_out, first, crank);
         KSP_HIP(hipMemcpyAsync(e->h_scal, scal, 120, hipMemcpyDeviceToHost, st));   // [0] max key, [2] keys, [6] entries, [9] / [14] overflow (one copy)
         // the kept-entry count sizes every later pass — but the label pass can be queued without it (its key count
         // comes from the device, its sampling rate from the kept fraction of the engine's previous build), so the
@@ -817,6 +826,9 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     }
     KSP_HIP(hipMemcpyAsync(e->h_scal + 2, scal + 2, 40, hipMemcpyDeviceToHost, st));   // [2] keys ... [6] entries (one copy)
     KSP_HIP(hipStreamSynchronize(st));   // the kept-entry count sizes every later pass
+    e->rank1_ok = true;   // (the prune scan writes a rank per kept entry)
+    if (e->h_scal[6])
+        hipLaunchKernelGGL(k_crank_from_rank, dim3(grid_for(e->h_scal[6] / CR_CHUNK + 1, bs)), dim3(bs), 0, st, rank1, crank, (u32)e->h_scal[6]);
     }
     m = e->h_scal[6];
     e->n_kept = m;
@@ -869,7 +881,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         phase_mark(e, st, "key groups");
         if (!(hand_zeroed && phase == 0)) KSP_HIP(hipMemsetAsync(d_kovf, 0, 8, st));   // (the hand-written partition's build zeroes the whole scalar block at its start)
         if (phase == 3) KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input only — are visited by no chunk)
-        hipLaunchKernelGGL((k_key_groups<V, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, rank1, firstp, newidx, (u32)m, U,
+        hipLaunchKernelGGL((k_key_groups<V, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, crank, firstp, newidx, (u32)m, U,
                            gsum, blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf,
                            std::getenv("KSP_DEBUG_COOP") ? std::max<u32>(KG_COOP, (u32)std::atoi(std::getenv("KSP_DEBUG_COOP"))) : KG_COOP,   // (timing experiments: raise the wave-per-key threshold)
                            huge_list);
@@ -966,6 +978,11 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         }
     }
     // ---- the block lists by sorting the entries by block -------------------------------------------------
+    if (!e->rank1_ok) {   // (the grouping wrote crank[] only: a rank per entry from first[])
+        const u32* fp = phase == 3 ? e->post_off : (const u32*)e->FK.p;
+        hipLaunchKernelGGL(k_rank_fill, dim3(1024), dim3(256), 0, st, fp, (u32)e->h_scal[2], rank1);
+        e->rank1_ok = true;
+    }
     if (reorder) hipLaunchKernelGGL((k_retag<V>), dim3(grid_for(m / (16 / sizeof(V)) + 1, bs)), dim3(bs), 0, st, VA, newidx, m);
     // sort 2: stable by block id (bits [8, 8+bbits) of the tag), payload = rank:  VA,rank1 -> VB,rk2
     u32* rk2 = (u32*)KA;                   // KA (sorted keys) is dead from here on
@@ -1171,7 +1188,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
-                        &e->d_wg, &e->gp, &e->gm, &e->ms_hist, &e->pmask, &e->PK, &e->PT, &e->PD, &e->parena, &e->PK2, &e->PT2, &e->PD2, &e->seg_tbl, &e->seg_grp, &e->seg_chk, &e->biglist, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
+                        &e->d_wg, &e->gp, &e->gm, &e->ms_hist, &e->pmask, &e->crank, &e->PK, &e->PT, &e->PD, &e->parena, &e->PK2, &e->PT2, &e->PD2, &e->seg_tbl, &e->seg_grp, &e->seg_chk, &e->biglist, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
                         &e->mr0, &e->mr1, &e->mstart};
     for (auto* b : bufs) b->release();
     if (e->h_count) (void)hipHostFree(e->h_count);

@@ -418,6 +418,11 @@ __global__ __launch_bounds__(256) void k_fix_runs(u64* __restrict__ keys, V* __r
 // (A single-kernel variant — bucket offsets by decoupled look-back, tickets for the order — was
 //  measured at 1.1 ms against 0.41 ms for the same kernel without the look-back: the persistent
 //  workgroups move in step, so every look-back walks hundreds of predecessors.  Two kernels it is.)
+// The key-by-key list build works on chunks of 4 096 kept entries and needs, per chunk, the rank of its first entry:
+// crank[c] = rank of entry c x 4 096.  Nothing else reads a rank per entry on the default path, so the grouping writes
+// these 1-in-4 096 ranks instead of 4 bytes for every kept entry (135 MB per C2 build); the sort-by-block fallback
+// expands first[] into the per-entry array when it needs it (k_rank_fill).
+constexpr u32 CR_CHUNK = 4096;
 constexpr u32 HB_CAP = 3072;     // entries per bucket (one 16-bit slot index each in LDS)
 constexpr u32 HB_SLOTS = 4096;   // hash slots per bucket (power of two; more than HB_CAP: never full)
 constexpr u32 HB_THREADS = 512;
@@ -575,7 +580,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict
                                                            const BucketBounds bb, const u32* __restrict__ big_list,
                                                            u32* __restrict__ overflow, u64* __restrict__ bsum,
                                                            const u64* __restrict__ bbase, V* __restrict__ vals2,
-                                                           u32* __restrict__ rank2, u32* __restrict__ first) {
+                                                           u32* __restrict__ rank2, u32* __restrict__ first, u32* __restrict__ crank) {
     constexpr u32 NT = HB_THREADS, NWV = NT / 64;
     constexpr unsigned long long EMPTY = ~0ull;
     __shared__ unsigned long long tkey[HB_SLOTS + 1];
@@ -646,7 +651,8 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict
             const u32 fill = atomicAdd(&tfill[sl], 1u);
             const u32 p = ebase + toff[sl] + fill, r = kbase + trank[sl];
             vals2[p] = vals[b0 + i];
-            rank2[p] = r;
+            if (rank2) rank2[p] = r;
+            if (p % CR_CHUNK == 0) crank[p / CR_CHUNK] = r;
             if (fill == 0) first[r] = p;
         }
     }
@@ -661,7 +667,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_emit(const u32* __restric
                                                             const BucketBounds bb, const u64* __restrict__ bbase,
                                                             const u64* __restrict__ bsum, u32 nbuckets,
                                                             V* __restrict__ vals2, u32* __restrict__ rank2,
-                                                            u32* __restrict__ first, u64* __restrict__ scal) {
+                                                            u32* __restrict__ first, u64* __restrict__ scal, u32* __restrict__ crank) {
     constexpr u32 NT = HB_THREADS, EPT = HB_CAP / NT;
     __shared__ u32 s_start[HB_EMIT], s_size[HB_EMIT];
     __shared__ u64 s_base[HB_EMIT], s_sum[HB_EMIT];
@@ -703,7 +709,8 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_emit(const u32* __restric
         const u32 ebase = (u32)base, kbase = (u32)(base >> 32), ke = (u32)sum, kk = (u32)(sum >> 32);
         for (u32 i = tid; i < ke; i += NT) {
             vals2[ebase + i] = o_tag[i];
-            rank2[ebase + i] = kbase + o_rank[i];
+            if (rank2) rank2[ebase + i] = kbase + o_rank[i];
+            if ((ebase + i) % CR_CHUNK == 0) crank[(ebase + i) / CR_CHUNK] = kbase + o_rank[i];
         }
         for (u32 i = tid; i < kk; i += NT) first[kbase + i] = ebase + o_first[i];
         __syncthreads();
@@ -806,10 +813,11 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
     __shared__ u32 s_idx[KG_CHUNK + KG_MAXC + 4];
     const u32 E0 = blockIdx.x * KG_CHUNK, E1 = min(m, E0 + KG_CHUNK);
     // the keys that start inside [E0, E1)
-    u32 r_lo = rank[E0];
+    static_assert(KG_CHUNK == CR_CHUNK, "crank[] holds the rank of every KG_CHUNK-th entry");
+    u32 r_lo = rank[blockIdx.x];   // (crank: the rank of entry E0)
     if (first[r_lo] != E0) ++r_lo;
     u32 r_hi = n_keys;
-    if (E1 < m) { r_hi = rank[E1]; if (first[r_hi] != E1) ++r_hi; }
+    if (E1 < m) { r_hi = rank[blockIdx.x + 1]; if (first[r_hi] != E1) ++r_hi; }
     if (r_lo >= r_hi) return;
     const u32 Eend = min(first[r_hi], E0 + KG_CHUNK + KG_MAXC);
     for (u32 i = threadIdx.x; E0 + i < Eend; i += KG_THREADS) s_idx[i] = newidx[src_of_tag(tag_of(vals[E0 + i]))];
@@ -914,6 +922,17 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
         }
         if (lane == 0) gsum[r] = (u64)groups | ((u64)bigs << 32);
     }
+}
+// crank[] from a per-entry rank array (the sort path and the postings input produce one) / the per-entry array from
+// first[] (the sort-by-block fallback after a grouping that only wrote crank[])
+__global__ void k_crank_from_rank(const u32* __restrict__ rank, u32* __restrict__ crank, const u32 m) {
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if ((u64)c * CR_CHUNK < m) crank[c] = rank[(size_t)c * CR_CHUNK];
+}
+__global__ void k_rank_fill(const u32* __restrict__ first, const u32 n_keys, u32* __restrict__ rank) {
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (u32 r = wave; r < n_keys; r += nwaves)
+        for (u32 e = first[r] + lane; e < first[r + 1]; e += 64) rank[e] = r;
 }
 // Keys with more than KG_MAXC holders (conserved k-mers of a large same-species collection), one workgroup
 // each: the holders are read from global memory once and OR-ed into an LDS table of 128-bit masks, one per
