@@ -605,7 +605,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         const int shiftb = topbit - pb;
         const u32 nbuckets = hand ? nb_hand : 1u << pb;
         // KB is free until the grouping scans: per-entry records, then the bucket tables
-        u32* rec = (u32*)e->KB.p;
+        unsigned short* rec = (unsigned short*)e->KB.p;   // (16 bits per partitioned entry; the tables behind keep their place)
         u64* bsum = (u64*)e->KB.p + ((seg ? nslots : nw) / 2 + 1);
         u64* bbase = bsum + nbuckets;
         u32* bstart = (u32*)(bbase + nbuckets);   // nbuckets + 1

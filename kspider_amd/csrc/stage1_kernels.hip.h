@@ -432,7 +432,9 @@ constexpr u32 HB_MEAN = 800;
 // The hand-written partition spreads the keys evenly over any number of buckets: the same mean the power-of-two
 // partition ends up with on real hash ranges (2^64 / scaled covers just over half of its power of two)
 constexpr u32 HB_HAND_MEAN = 2000, HB_HAND_MEAN_MAX = 2400;
-constexpr u32 HB_KEPT = 1u << 31, HB_FIRST = 1u << 30;   // per-entry record: kept | first of its key | rank << 12 | place
+constexpr u32 HB_KEPT = 1u << 15, HB_FIRST = 1u << 14;   // per-entry record (16 bits): kept | first of its key | place inside the
+                                                         // bucket's kept entries (< 4 096); the key's rank is the number of
+                                                         // "first" places below — counted by k_bucket_emit, not stored
 constexpr u32 HB_EMIT = 8;       // buckets per workgroup of the emit kernel
 constexpr u32 HB_BIG_DISTINCT = 3072;   // k_bucket_big: distinct keys per oversize bucket (any number of such buckets: the list holds one slot per bucket)
 
@@ -462,7 +464,7 @@ __global__ void k_bucket_bounds(const u64* __restrict__ keys, u64 n, int shiftb,
 // and then the keys of the workgroup's next bucket are already on their way (the kernel is a chain
 // of memory round trips otherwise).  bsum[] is zero at launch (trailing empty buckets are not visited).
 __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __restrict__ keys, const BucketBounds bb,
-                                                             u32 nbuckets, u32 nw, u32* __restrict__ rec,
+                                                             u32 nbuckets, u32 nw, unsigned short* __restrict__ rec,
                                                              u64* __restrict__ bsum, u32* __restrict__ overflow,
                                                              u32* __restrict__ big_list) {
     constexpr u32 NT = HB_THREADS, NWV = NT / 64;
@@ -559,9 +561,9 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
             if (((tcnt2[sl >> 1] >> (16 * (sl & 1))) & 0xFFFFu) >= 2) {
                 const u32 fill = atomicAdd(&tfill[sl], 1u);
                 const u32 t = toff[sl];
-                r = HB_KEPT | (fill == 0 ? HB_FIRST : 0u) | ((t >> 16) << 12) | ((t & 0xFFFFu) + fill);
+                r = HB_KEPT | (fill == 0 ? HB_FIRST : 0u) | ((t & 0xFFFFu) + fill);
             }
-            rec[b0 + i] = r;
+            rec[b0 + i] = (unsigned short)r;
         }
         b = bn; b0 = n0; raw = nraw; size = nsize;
 #pragma unroll
@@ -663,17 +665,18 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict
 // The places inside a bucket are a random permutation (slot order), so a bucket's output is put in
 // order in LDS and leaves in full lines.  One workgroup handles HB_EMIT consecutive buckets.
 template <class V>
-__global__ __launch_bounds__(HB_THREADS) void k_bucket_emit(const u32* __restrict__ rec, const V* __restrict__ vals,
+__global__ __launch_bounds__(HB_THREADS) void k_bucket_emit(const unsigned short* __restrict__ rec, const V* __restrict__ vals,
                                                             const BucketBounds bb, const u64* __restrict__ bbase,
                                                             const u64* __restrict__ bsum, u32 nbuckets,
                                                             V* __restrict__ vals2, u32* __restrict__ rank2,
                                                             u32* __restrict__ first, u64* __restrict__ scal, u32* __restrict__ crank) {
-    constexpr u32 NT = HB_THREADS, EPT = HB_CAP / NT;
+    constexpr u32 NT = HB_THREADS, EPT = HB_CAP / NT, FW = HB_CAP / 32;
     __shared__ u32 s_start[HB_EMIT], s_size[HB_EMIT];
     __shared__ u64 s_base[HB_EMIT], s_sum[HB_EMIT];
     __shared__ V o_tag[HB_CAP];
-    __shared__ unsigned short o_rank[HB_CAP], o_first[HB_CAP / 2];
-    const u32 tid = threadIdx.x;
+    __shared__ u32 s_fb2[2][FW], s_fpre[FW];   // bit p: a key's entries begin at place p (two bitmaps: the next bucket's is
+                                               // cleared while this one's is read); keys below word w
+    const u32 tid = threadIdx.x, lane = tid & 63;
     const u32 g0 = blockIdx.x * HB_EMIT;
     if (tid < HB_EMIT) {
         const bool in = g0 + tid < nbuckets;
@@ -682,11 +685,16 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_emit(const u32* __restric
         s_base[tid] = in ? bbase[g0 + tid] : 0;
         s_sum[tid] = in ? bsum[g0 + tid] : 0;
     }
+    if (tid < 2 * FW) (&s_fb2[0][0])[tid] = 0;
     __syncthreads();
+    u32 flip = 0;
     for (u32 q = 0; q < HB_EMIT; ++q) {
         const u32 b0 = s_start[q], size = s_size[q];
         const u64 sum = s_sum[q];
         if (sum == 0 || size > HB_CAP) continue;   // nothing kept (or a bucket the group kernel skipped)
+        u32* const s_fbits = s_fb2[flip];
+        u32* const s_fnext = s_fb2[flip ^ 1];
+        flip ^= 1;
         u32 r[EPT];
         V t[EPT];
 #pragma unroll
@@ -698,21 +706,37 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_emit(const u32* __restric
 #pragma unroll
         for (u32 j = 0; j < EPT; ++j) {
             if (r[j] & HB_KEPT) {
-                const u32 place = r[j] & 0xFFFu, rk = (r[j] >> 12) & 0xFFFu;
+                const u32 place = r[j] & 0xFFFu;
                 o_tag[place] = t[j];
-                o_rank[place] = (unsigned short)rk;
-                if (r[j] & HB_FIRST) o_first[rk] = (unsigned short)place;
+                if (r[j] & HB_FIRST) atomicOr(&s_fbits[place >> 5], 1u << (place & 31));
             }
         }
         __syncthreads();
+        if (tid < 64) {   // keys in front of every word of the bitmap (96 words: two per lane of one wave)
+            static_assert(FW <= 128, "two bitmap words per lane");
+            const u32 c0 = lane < FW ? (u32)__popc(s_fbits[lane]) : 0u, c1 = 64 + lane < FW ? (u32)__popc(s_fbits[64 + lane]) : 0u;
+            u32 i0 = c0, i1 = c1;
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 u0 = __shfl_up(i0, o), u1 = __shfl_up(i1, o);
+                if ((int)lane >= o) { i0 += u0; i1 += u1; }
+            }
+            const u32 tot0 = __shfl(i0, 63);
+            if (lane < FW) s_fpre[lane] = i0 - c0;
+            if (64 + lane < FW) s_fpre[64 + lane] = tot0 + i1 - c1;
+        }
+        __syncthreads();
         const u64 base = s_base[q];
-        const u32 ebase = (u32)base, kbase = (u32)(base >> 32), ke = (u32)sum, kk = (u32)(sum >> 32);
+        const u32 ebase = (u32)base, kbase = (u32)(base >> 32), ke = (u32)sum;
         for (u32 i = tid; i < ke; i += NT) {
             vals2[ebase + i] = o_tag[i];
-            if (rank2) rank2[ebase + i] = kbase + o_rank[i];
-            if ((ebase + i) % CR_CHUNK == 0) crank[(ebase + i) / CR_CHUNK] = kbase + o_rank[i];
+            const u32 w = s_fbits[i >> 5], below = s_fpre[i >> 5] + (u32)__popc(w & ((1u << (i & 31)) - 1u));   // keys that begin below place i
+            const bool head = (w >> (i & 31)) & 1u;
+            const u32 rk = kbase + below - (head ? 0u : 1u);   // rank of the key place i belongs to
+            if (head) first[kbase + below] = ebase + i;
+            if (rank2) rank2[ebase + i] = rk;
+            if ((ebase + i) % CR_CHUNK == 0) crank[(ebase + i) / CR_CHUNK] = rk;
         }
-        for (u32 i = tid; i < kk; i += NT) first[kbase + i] = ebase + o_first[i];
+        if (tid < FW) s_fnext[tid] = 0;   // (the bitmap of the bucket after this one: last read two barriers ago)
         __syncthreads();
     }
     if (g0 + HB_EMIT >= nbuckets && tid == 0) {
