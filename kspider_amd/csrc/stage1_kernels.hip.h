@@ -448,6 +448,11 @@ struct BucketBounds {
     __device__ u32 size(const u32 b) const { return cap ? min(cnt[b], cap) : start[b + 1] - start[b]; }
 };
 
+// slot of a key in a bucket's table (12 bits; the callers mask to their table size): the halves of the key folded, one
+// 32-bit multiply (a 64 x 64 multiply is six quarter-rate vector multiplies per entry — a tenth of k_bucket_group).  The
+// keys of a bucket agree in their top bits only, so the fold keeps what distinguishes them.
+__device__ inline u32 hb_slot(const unsigned long long key) { return (((u32)key ^ (u32)(key >> 32)) * 0x9E3779B1u) >> 20; }
+
 __global__ void k_bucket_bounds(const u64* __restrict__ keys, u64 n, int shiftb, u32 nbuckets, u32* __restrict__ bstart) {
     const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b > nbuckets) return;
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
             if (key == EMPTY) {
                 h = slots;   // the one key that looks like an empty slot has a slot of its own
             } else {
-                h = (u32)((key * 0x9E3779B97F4A7C15ull) >> 52) & (slots - 1);
+                h = hb_slot(key) & (slots - 1);
                 while (true) {
                     const unsigned long long prev = atomicCAS(&tkey[h], EMPTY, key);
                     if (prev == EMPTY || prev == key) break;
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict
     __syncthreads();
     auto slot_of = [&](const unsigned long long key, const bool insert) -> u32 {
         if (key == EMPTY) return HB_SLOTS;
-        u32 h = (u32)((key * 0x9E3779B97F4A7C15ull) >> 52) & (HB_SLOTS - 1);
+        u32 h = hb_slot(key) & (HB_SLOTS - 1);
         while (true) {
             if (insert) {
                 const unsigned long long prev = atomicCAS(&tkey[h], EMPTY, key);
