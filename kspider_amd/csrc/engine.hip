@@ -926,22 +926,32 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             u64* sval = (u64*)KA;             // (the per-key counts and offsets are dead once the records are packed)
             e->have_dwork = work != nullptr;
             const char* msv = std::getenv("KSP_MS");   // 0: the library sort (diagnostic / tests)
-            if (nb <= MS_MAXB && K <= (u64)256 * MS_PER * MS_CHUNK && !(msv && std::atoi(msv) == 0)) {
+            // (up to 256 blocks; the 1 024-block tables are slower than the library's two radix passes — C3: block lists 1.04 -> 1.38 ms
+            //  for 0.23 ms of join, C4 4.1 -> 5.3 — and only run when KSP_MS=1024 asks for them: tests)
+            const u32 ms_max = (msv && std::atoi(msv) == 1024) ? MS_MAXB : 256u;
+            if (nb <= ms_max && Kcap / MS_CHUNK < (1u << 20) && !(msv && std::atoi(msv) == 0)) {
                 // stable split of the records on the block id, written straight into the padded lists (stage1_kernels: k_ms_*)
+                const u32 mb = nb <= 256 ? 256u : 1024u;   // table size (two instantiations)
                 const u32 chunks_cap = grid_for(Kcap, MS_CHUNK), chunks = grid_for(K, MS_CHUNK);
-                if ((rc = e->ms_hist.ensure(((size_t)chunks_cap + 1) * MS_MAXB * 4))) return rc;
-                hipLaunchKernelGGL(k_ms_hist, dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, scal, e->ms_hist.as<u32>());
-                hipLaunchKernelGGL(k_ms_scan, dim3(nb), dim3(256), 0, st, e->ms_hist.as<u32>(), scal, e->ms_hist.as<u32>() + (size_t)chunks_cap * MS_MAXB, blk_raw,
-                                   blk_pos, nb);
+                if ((rc = e->ms_hist.ensure(((size_t)chunks_cap + 1) * mb * 4 + 4096))) return rc;
+                u32* hist = e->ms_hist.as<u32>();
+                u32* tot = hist + (size_t)chunks_cap * mb;
+                if (mb == 256) hipLaunchKernelGGL(k_ms_hist<256>, dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, scal, hist);
+                else hipLaunchKernelGGL(k_ms_hist<1024>, dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, scal, hist);
+                hipLaunchKernelGGL(k_ms_scan, dim3(nb), dim3(256), 0, st, hist, mb, scal, tot, blk_raw, blk_pos, nb);
                 hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
                 uint4* pm = nullptr;
-                if (!W) {   // unweighted lists: the join's bit-sliced paths read the masks at the list positions
+                if (!W && m >= 4 * K) {   // unweighted lists with multi-source postings (no match records: the rule of
+                                          // launch_sched_kernels): the join's bit-sliced paths read the masks at the list positions
                     if ((rc = e->pmask.ensure((Kcap + (u64)nb * (WIN + 4) + 4 * WIN) * 16))) return rc;
                     pm = e->pmask.as<uint4>();
                 }
-                hipLaunchKernelGGL((k_ms_place<W>), dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, rec_val, scal, e->ms_hist.as<u32>(),
-                                   blk_pos, nb, wkey, e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr,
-                                   e->mm.as<uint4>(), pm);
+                if (mb == 256)
+                    hipLaunchKernelGGL((k_ms_place<W, 256>), dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, rec_val, scal, hist, blk_pos, nb, wkey,
+                                       e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, e->mm.as<uint4>(), pm);
+                else
+                    hipLaunchKernelGGL((k_ms_place<W, 1024>), dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, rec_val, scal, hist, blk_pos, nb, wkey,
+                                       e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, e->mm.as<uint4>(), pm);
                 e->pmask_on = pm != nullptr;
             } else {
             tb = 0;   // (temporary storage for the bound, not for this build's K: K moves a little from build to build — the labels'

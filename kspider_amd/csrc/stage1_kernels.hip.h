@@ -1168,42 +1168,46 @@ __global__ void k_place_groups(const u32* __restrict__ sblk, const u64* __restri
 // block and into the block tables (k_ms_scan: what k_blk_raw_pos searched for), and k_ms_place ranks the records of its
 // chunk — equal blocks inside a wave by eight ballots, waves and rounds through a small LDS table — and writes ranks
 // and posting words straight into the padded lists.
-constexpr u32 MS_CHUNK = 2048, MS_THREADS = 256, MS_ROUNDS = MS_CHUNK / MS_THREADS, MS_MAXB = 256;
+constexpr u32 MS_CHUNK = 2048, MS_THREADS = 256, MS_ROUNDS = MS_CHUNK / MS_THREADS;
+constexpr u32 MS_MAXB = 1024;         // blocks the split takes (two instantiations: tables of 256 or 1 024 blocks)
 constexpr u32 PM_BIG = 0xE0000000u;   // (= BIG: posting word with a mask index)
+template <u32 MB>
 __global__ __launch_bounds__(MS_THREADS) void k_ms_hist(const u32* __restrict__ rec_blk, u64* __restrict__ scal,
                                                          u32* __restrict__ hist) {
-    __shared__ u32 s_h[MS_MAXB];
+    __shared__ u32 s_h[MB];
     const u32 n = (u32)scal[1];   // groups (k_group_totals)
     const u32 g0 = blockIdx.x * MS_CHUNK;
     if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<u32*>(scal + 15)[0] = 0;   // k_ms_scan's "workgroups done"
     if (g0 >= n) return;
-    s_h[threadIdx.x] = 0;
+    for (u32 i = threadIdx.x; i < MB; i += MS_THREADS) s_h[i] = 0;
     __syncthreads();
     for (u32 k = 0; k < MS_ROUNDS; ++k) {
         const u32 g = g0 + k * MS_THREADS + threadIdx.x;
-        if (g < n) atomicAdd(&s_h[rec_blk[g] & (MS_MAXB - 1)], 1u);
+        if (g < n) atomicAdd(&s_h[rec_blk[g] & (MB - 1)], 1u);
     }
     __syncthreads();
-    hist[(size_t)blockIdx.x * MS_MAXB + threadIdx.x] = s_h[threadIdx.x];
+    for (u32 i = threadIdx.x; i < MB; i += MS_THREADS) hist[(size_t)blockIdx.x * MB + i] = s_h[i];
 }
 // hist[c][b] -> groups of block b in the chunks before c; blk_raw / blk_pos as k_blk_raw_pos leaves them.  One
-// workgroup per block: every thread takes up to 16 consecutive chunks of the block's column (all loads in flight), the
-// workgroup scans the thread sums, the running sums go back; the workgroup that finishes last (a counter in the
-// scalar block, zeroed by k_ms_hist) lays out the block tables.
-constexpr u32 MS_PER = 16;   // chunks per thread: 256 x 16 x 2 048 = 8.4 M groups (more: the library sort)
-__global__ __launch_bounds__(256) void k_ms_scan(u32* __restrict__ hist, u64* __restrict__ scal, u32* __restrict__ tot,
-                                                 u32* __restrict__ blk_raw, u32* __restrict__ blk_pos, const u32 nb) {
+// workgroup per block: every thread takes a run of consecutive chunks of the block's column, 16 loads in flight at a
+// time (sum, then — after the workgroup's scan of the thread sums — running sums written back); the workgroup that
+// finishes last (a counter in the scalar block, zeroed by k_ms_hist) lays out the block tables.
+constexpr u32 MS_PER = 16;
+__global__ __launch_bounds__(256) void k_ms_scan(u32* __restrict__ hist, const u32 stride, u64* __restrict__ scal,
+                                                 u32* __restrict__ tot, u32* __restrict__ blk_raw, u32* __restrict__ blk_pos,
+                                                 const u32 nb) {
     __shared__ u32 s_w[4], s_last;
     const u32 n = (u32)scal[1];
-    const u32 chunks = (n + MS_CHUNK - 1) / MS_CHUNK, per = (chunks + 255u) / 256u;   // (<= MS_PER: checked by the host)
+    const u32 chunks = (n + MS_CHUNK - 1) / MS_CHUNK, per = (chunks + 255u) / 256u;
     const u32 b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    u32 h[MS_PER];
+    const u32 c0 = tid * per, c1 = min(chunks, c0 + per);
     u32 sum = 0;
+    for (u32 cb = c0; cb < c1; cb += MS_PER) {
+        u32 h[MS_PER];
 #pragma unroll
-    for (u32 i = 0; i < MS_PER; ++i) {
-        const u32 c = tid * per + i;
-        h[i] = (i < per && c < chunks) ? hist[(size_t)c * MS_MAXB + b] : 0u;
-        sum += h[i];
+        for (u32 i = 0; i < MS_PER; ++i) h[i] = cb + i < c1 ? hist[(size_t)(cb + i) * stride + b] : 0u;
+#pragma unroll
+        for (u32 i = 0; i < MS_PER; ++i) sum += h[i];
     }
     u32 inc = sum;
     for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
@@ -1211,11 +1215,15 @@ __global__ __launch_bounds__(256) void k_ms_scan(u32* __restrict__ hist, u64* __
     __syncthreads();
     u32 run = inc - sum, total = 0;
     for (u32 w = 0; w < 4; ++w) { if (w < wv) run += s_w[w]; total += s_w[w]; }
+    for (u32 cb = c0; cb < c1; cb += MS_PER) {
+        u32 h[MS_PER];
 #pragma unroll
-    for (u32 i = 0; i < MS_PER; ++i) {
-        const u32 c = tid * per + i;
-        if (i < per && c < chunks) hist[(size_t)c * MS_MAXB + b] = run;
-        run += h[i];
+        for (u32 i = 0; i < MS_PER; ++i) h[i] = cb + i < c1 ? hist[(size_t)(cb + i) * stride + b] : 0u;
+#pragma unroll
+        for (u32 i = 0; i < MS_PER; ++i) {
+            if (cb + i < c1) hist[(size_t)(cb + i) * stride + b] = run;
+            run += h[i];
+        }
     }
     if (tid == 0) {
         tot[b] = total;
@@ -1226,7 +1234,7 @@ __global__ __launch_bounds__(256) void k_ms_scan(u32* __restrict__ hist, u64* __
     if (!s_last) return;
     __threadfence();
     __shared__ u32 s_t[MS_MAXB];
-    s_t[tid] = tid < nb ? __hip_atomic_load(&tot[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;   // (one round trip, not one per block)
+    for (u32 i = tid; i < nb; i += 256) s_t[i] = __hip_atomic_load(&tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (one round trip, not one per block)
     __syncthreads();
     if (tid != 0) return;
     u32 raw = 0, pos = 0;
@@ -1241,49 +1249,50 @@ __global__ __launch_bounds__(256) void k_ms_scan(u32* __restrict__ hist, u64* __
     blk_pos[nb] = pos;
     scal[3] = pos;
 }
-template <bool W>
+template <bool W, u32 MB>
 __global__ __launch_bounds__(MS_THREADS) void k_ms_place(const u32* __restrict__ rec_blk, const u64* __restrict__ rec_val,
                                                           const u64* __restrict__ scal, const u32* __restrict__ base,
                                                           const u32* __restrict__ blk_pos, const u32 nb, const u32* __restrict__ wkey,
                                                           u32* __restrict__ brk, u32* __restrict__ info, u32* __restrict__ bw,
                                                           const uint4* __restrict__ bigmask, uint4* __restrict__ pmask) {
-    constexpr u32 NWV = MS_THREADS / 64;
-    __shared__ u32 s_cnt[MS_ROUNDS * NWV][MS_MAXB];   // records of block b in (round, wave) slot; then: records before the slot
-    __shared__ u32 s_dst[MS_MAXB];                    // first place of this chunk's records of block b in the padded list
+    constexpr u32 NWV = MS_THREADS / 64, NSL = MS_ROUNDS * NWV, BITS = MB == 256 ? 8u : 10u;
+    static_assert(MB == 256 || MB == 1024, "two table sizes");
+    __shared__ unsigned short s_cnt[NSL][MB];   // records of block b in (round, wave) slot (<= 64); then: records before the slot (< 2 048)
+    __shared__ u32 s_dst[MB];                   // first place of this chunk's records of block b in the padded list
     const u32 n = (u32)scal[1];
     const u32 g0 = blockIdx.x * MS_CHUNK;
     if (g0 >= n) return;
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (u32 i = tid; i < MS_ROUNDS * NWV * MS_MAXB; i += MS_THREADS) (&s_cnt[0][0])[i] = 0;
-    s_dst[tid] = (tid < nb ? blk_pos[tid] : 0u) + base[(size_t)blockIdx.x * MS_MAXB + tid];
+    for (u32 i = tid; i < NSL * MB / 2; i += MS_THREADS) reinterpret_cast<u32*>(&s_cnt[0][0])[i] = 0;
+    for (u32 i = tid; i < MB; i += MS_THREADS) s_dst[i] = (i < nb ? blk_pos[i] : 0u) + base[(size_t)blockIdx.x * MB + i];
     u32 blk[MS_ROUNDS], rk[MS_ROUNDS];
     u64 val[MS_ROUNDS];
 #pragma unroll
     for (u32 k = 0; k < MS_ROUNDS; ++k) {
         const u32 g = g0 + k * MS_THREADS + tid;
-        blk[k] = g < n ? (rec_blk[g] & (MS_MAXB - 1)) : ~0u;
+        blk[k] = g < n ? (rec_blk[g] & (MB - 1)) : ~0u;
         val[k] = g < n ? rec_val[g] : 0;
     }
     __syncthreads();
 #pragma unroll
     for (u32 k = 0; k < MS_ROUNDS; ++k) {
-        // lanes of this wave with the same block: eight ballots
+        // lanes of this wave with the same block: one ballot per bit of the block id
         unsigned long long m = __ballot(blk[k] != ~0u);
 #pragma unroll
-        for (u32 bit = 0; bit < 8; ++bit) {
+        for (u32 bit = 0; bit < BITS; ++bit) {
             const unsigned long long bal = __ballot((blk[k] >> bit) & 1u);
             m &= ((blk[k] >> bit) & 1u) ? bal : ~bal;
         }
         const unsigned long long below = m & ((1ull << lane) - 1ull);
         rk[k] = (u32)__popcll(below);
-        if (blk[k] != ~0u && below == 0) s_cnt[k * NWV + wv][blk[k]] = (u32)__popcll(m);   // (the first lane of every block present)
+        if (blk[k] != ~0u && below == 0) s_cnt[k * NWV + wv][blk[k]] = (unsigned short)__popcll(m);   // (the first lane of every block present)
     }
     __syncthreads();
-    {   // per block: records in the slots before each (round, wave) slot
+    for (u32 bq = tid; bq < MB; bq += MS_THREADS) {   // per block: records in the slots before each (round, wave) slot
         u32 run = 0;
-        for (u32 sl = 0; sl < MS_ROUNDS * NWV; ++sl) {
-            const u32 c = s_cnt[sl][tid];
-            s_cnt[sl][tid] = run;
+        for (u32 sl = 0; sl < NSL; ++sl) {
+            const u32 c = s_cnt[sl][bq];
+            s_cnt[sl][bq] = (unsigned short)run;
             run += c;
         }
     }

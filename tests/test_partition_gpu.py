@@ -181,3 +181,22 @@ def test_segment_partition_shapes(oracle_lib, monkeypatch):
     assert st["partition_kind"] == 2 and st["partition_fallback"] == 5, st        # a bucket overflowed: paged partition
     ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
     assert len(edges) == len(ref) and (edges == ref).all()
+
+
+def test_stable_split_of_the_group_records_up_to_1024_blocks(oracle_lib, monkeypatch):
+    """24 000 sources of a dozen hashes: 283 blocks with the spare ones — above the 256 the hand-written split of the
+    group records takes by default.  Library sort (default there), the split's 1 024-block tables (KSP_MS=1024: 16-bit
+    counters, ten ballots, positional masks for the join) and KSP_MS=0 give the same edges as the restated reference."""
+    sk = synth.generate("C5", n_sources=24000, seed=777)
+    co, src, w = oracle_lib.build_colors(sk.keys, sk.offsets)
+    _, n_edges, _, ref = oracle_lib.accumulate_mem(co, src, w, 8)
+    ref = np.sort(ref, order=["source_1", "source_2"])
+    for ms in (None, "1024", "0"):
+        monkeypatch.delenv("KSP_MS", raising=False)
+        if ms is not None:
+            monkeypatch.setenv("KSP_MS", ms)
+        edges, st = engine.pairwise_host(sk.keys, sk.offsets)
+        assert st["n_blocks"] > 256, st
+        assert len(edges) == n_edges == len(ref)
+        assert (edges["source_1"] + 1 == ref["source_1"]).all() and (edges["source_2"] + 1 == ref["source_2"]).all()
+        assert (edges["shared"] == ref["shared"]).all()
