@@ -85,6 +85,8 @@ def lib():
         L.ksp_engine_join.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p,
                                       ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p]
         L.ksp_engine_get_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(Stats)]
+        L.ksp_engine_join_launch.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+        L.ksp_engine_join_wait.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.ksp_engine_build_slice.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                              ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32,
                                              ctypes.c_void_p]
@@ -326,15 +328,11 @@ class Engine:
 
     def join_launch(self, t0: int, t1: int, d_edges_ptr: int, capacity: int, stream: int = 0) -> None:
         """Queue the join on `stream` and return; join_wait() collects the count (see include/kspider_amd.h)."""
-        L = lib()
-        L.ksp_engine_join_launch.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
-        _check(L.ksp_engine_join_launch(self._h, t0, t1, d_edges_ptr or None, capacity, ctypes.c_void_p(stream)))
+        _check(lib().ksp_engine_join_launch(self._h, t0, t1, d_edges_ptr or None, capacity, ctypes.c_void_p(stream)))
 
     def join_wait(self) -> int:
-        L = lib()
-        L.ksp_engine_join_wait.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         cnt = ctypes.c_uint64(0)
-        _check(L.ksp_engine_join_wait(self._h, ctypes.byref(cnt)))
+        _check(lib().ksp_engine_join_wait(self._h, ctypes.byref(cnt)))
         return int(cnt.value)
 
     def join(self, t0: int, t1: int, d_edges_ptr: int, capacity: int, stream: int = 0) -> int:
@@ -358,6 +356,12 @@ class Engine:
         st = Stats()
         _check(lib().ksp_engine_get_stats(self._h, ctypes.byref(st)))
         return st.as_dict()
+
+    def ms_join(self) -> float:
+        """HIP-event time of the last collected join (one field of the stats, without building the dict)."""
+        st = Stats()
+        _check(lib().ksp_engine_get_stats(self._h, ctypes.byref(st)))
+        return float(st.ms_join)
 
 
 class DeviceBuffer:
