@@ -59,16 +59,21 @@ typedef struct ksp_stats {
     float ms_sort;              /* its HIP-event time (all passes + histogram)                        */
     int sort_bits;              /* key bits it sorted on                                              */
     int partition_kind;         /* how the last build brought equal keys together: 0 nothing to do / postings
-                                   input, 1 rocPRIM radix partition or sort, 2 the hand-written two-level
-                                   partition (partition_kernels.hip.h)                                   */
-    int partition_fallback;     /* 0, or why the hand-written partition handed the build to rocPRIM: 1 page
-                                   table / pool full (keys far from uniform), 2 internal count mismatch,
-                                   3 page wait timed out — 2 and 3 are defects, never expected            */
+                                   input, 1 rocPRIM radix partition or sort, 2 the hand-written paged
+                                   partition, 3 the segment partition: level 1 read off the sorted runs
+                                   (partition_kernels.hip.h)                                             */
+    int partition_fallback;     /* 0, or why a hand-written partition handed the build on: 1 page table / pool
+                                   full (keys far from uniform; -> rocPRIM), 2 internal count mismatch, 3 page
+                                   wait timed out (2 and 3 are defects, never expected), 4 / 5 a tile / a bucket
+                                   of the segment partition overflowed (-> the paged partition)           */
     uint64_t n_match_records;   /* match-list join: (key, block pair) records stage 1 handed to the join (0: the
                                    join searches the block lists)                                         */
     uint64_t n_join_workgroups; /* shares of the work list (workgroups of a join over all tiles)           */
     uint64_t n_kept_entries;    /* entries whose key is held by at least two sources (the others are pruned) */
     uint64_t n_kept_keys;       /* distinct keys among them                                                */
+    int stage1_kind;            /* middle of stage 1: 1 bucket-resident (grouping + emit + labels in one kernel, group
+                                   records straight to rank order: fused_kernels.hip.h), 0 pass by pass      */
+    int reserved_;
 } ksp_stats;
 
 const char* ksp_last_error(void);

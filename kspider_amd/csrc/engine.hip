@@ -44,6 +44,7 @@
 
 #include "../../include/kspider_amd.h"
 #include "engine_internal.h"
+#include "host_sync.h"
 
 typedef uint64_t u64;
 typedef uint32_t u32;
@@ -73,6 +74,7 @@ constexpr u32 INLINE_MAX = 4;         // sources whose 7-bit ids fit into the po
 
 #include "stage1_kernels.hip.h"
 #include "partition_kernels.hip.h"
+#include "fused_kernels.hip.h"
 #include "join_kernels.hip.h"
 
 // ------------------------------------------------------------------------------------
@@ -138,6 +140,10 @@ struct ksp_engine {
     float ph_ms[kMaxPhase] = {};
     u32 hb_slots = 0;             // workgroups of k_bucket_group the device holds at once
     bool key_groups_off = false;  // a key has too many holders for the key-by-key list build: sort the entries by block
+    bool fused_off = false;       // the bucket-resident middle of stage 1 (fused_kernels.hip.h) cannot take these keys (an oversize bucket,
+                                  // sparse sharing that wants match records): the pass-by-pass kernels from now on
+    bool fused_flags = false;     // the tile flags and the diagonal work of this build were written with the block lists (k_fms_place, k_fkeys)
+    int fused_used = 0;           // (stats) the last build took the bucket-resident path
     bool have_rank_pairs = false; // gp holds (block, rank) of every list word in rank order (key-by-key build)
     bool have_dwork = false;      // ... and dwork the diagonal work / holder sums (k_move_groups)
     ksp::Buf gp, gm, ms_hist;     // group records of the key-by-key build; parked masks; per-chunk block counts of the split (k_ms_*)
@@ -734,6 +740,143 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         e->sort_entries = nw;
         e->sort_bits = pb;
         e->part_kind = (seg || seg3_used) ? 3 : hand ? 2 : 1;
+        // ---- the bucket-resident middle of stage 1 (fused_kernels.hip.h): grouping + emit + labels in one kernel, the
+        // group records straight to rank order, one read-back.  Unweighted whole builds on the hand-written partition
+        // whose blocks fit the split's tables; anything it cannot take (an oversize bucket, sparse sharing) sets
+        // fused_off and the build is repeated pass by pass (KSP_FUSED=0 forces that: tests run both).
+        e->fused_flags = false;
+        e->fused_used = 0;
+        if constexpr (!W) {
+            const char* fv = std::getenv("KSP_FUSED");
+            const char* msv = std::getenv("KSP_MS");
+            const u32 ms_max = (msv && std::atoi(msv) == 1024) ? MS_MAXB : 256u;
+            const u64 Tt = (u64)nb * (nb + 1) / 2;
+            if (hand && phase == 0 && reorder && nb <= ms_max && nb <= FK_NB_MAX && Tt <= (1ull << 22) && !e->fused_off && !e->key_groups_off &&
+                !(fv && std::atoi(fv) == 0) && !(msv && std::atoi(msv) == 0) && e->pre_zeroed_bits && e->pre_zeroed_work) {
+                if ((rc = e->biglist.ensure(((size_t)nbuckets + 1) * 4))) return rc;
+                if ((rc = e->VA.ensure((nslots + 4) * sizeof(V)))) return rc;
+                if ((rc = e->FK.ensure((nslots / 2 + (u64)nbuckets + 16) * 4))) return rc;
+                if ((rc = e->mm.ensure((nslots / (INLINE_MAX + 1) + 16) * 16))) return rc;
+                VA = e->VA.as<V>();
+                u32* kst = (u32*)e->FK.p;
+                if (!e->hb_slots) {
+                    int per_cu = 0, cus = 0;
+                    KSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bucket_group, HB_THREADS, 0));
+                    KSP_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+                    e->hb_slots = (u32)std::max(1, per_cu * cus);
+                }
+                // labels on lines of their own while they are lowered (the head of KB: no per-entry records on this path)
+                const u32 skip = label_sampling(e, (u64)((double)nw * e->kept_frac));
+                const int ls = e->KB.bytes >= (size_t)N * 128 && (size_t)N * 128 <= (size_t)(nslots / 2) * 8 ? 5 : 0;
+                u32* lab = ls ? (u32*)e->KB.p : label;
+                if (ls) hipLaunchKernelGGL(k_label_spread, dim3(grid_for(N, bs)), dim3(bs), 0, st, lab, ls, N);
+                hipLaunchKernelGGL((k_fgroup<V>), dim3(std::min(nbuckets, e->hb_slots)), dim3(HB_THREADS), 0, st, KA, VB, bb, nbuckets, VA, kst,
+                                   bsum, d_hovf, e->biglist.as<u32>(), lab, ls, skip, label_max);
+                size_t tb2 = 0;
+                KSP_HIP(rocprim::exclusive_scan(nullptr, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
+                if ((rc = e->tmp.ensure(tb2))) return rc;
+                KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb2, bsum, bbase, (u64)0, (size_t)nbuckets, rocprim::plus<u64>(), st));
+                hipLaunchKernelGGL(k_ftotals, dim3(1), dim3(64), 0, st, bsum, bbase, nbuckets, scal);
+                phase_mark(e, st, "source labels + order");
+                if (ls) hipLaunchKernelGGL(k_label_gather, dim3(grid_for(N, bs)), dim3(bs), 0, st, lab, ls, label, N);
+                {
+                    int lbits = 1;
+                    while (lbits < 32 && (N >> lbits)) ++lbits;
+                    tb = 0;
+                    u32* sort_out = e->padded ? sorted_src : order;
+                    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, label, labs, iota, sort_out, (size_t)N, 0, lbits, st));
+                    if ((rc = e->tmp.ensure(tb))) return rc;
+                    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, label, labs, iota, sort_out, (size_t)N, 0, lbits, st));
+                    if (e->padded) {
+                        hipLaunchKernelGGL(k_pack_blocks, dim3(1), dim3(1024), 0, st, labs, N, nb, blk_src);
+                        hipLaunchKernelGGL(k_place_sources, dim3(grid_for((u64)nb * TB, bs)), dim3(bs), 0, st, sorted_src, blk_src, newidx, order,
+                                           sbound, e->blk_max.as<u32>(), nb);
+                    } else {
+                        hipLaunchKernelGGL(k_perm_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, newidx, sbound, e->blk_max.as<u32>(), N);
+                    }
+                }
+                // the (block, key) groups, chunk by chunk, straight into rank order
+                phase_mark(e, st, "key groups");
+                u32 gb = 8;
+                if (const char* gv = std::getenv("KSP_DEBUG_FK_GB")) gb = (u32)std::max(1, std::atoi(gv));   // (timing experiments)
+                const u32 chunks = grid_for(nbuckets, gb);
+                const u32 mb = nb <= 256 ? 256u : 1024u;
+                const u64 Kcap = nw;   // records <= kept entries <= entries
+                if ((rc = e->gp.ensure((Kcap + 4) * 12))) return rc;
+                e->gp_stride = Kcap + 4;
+                u64* rec_val = e->gp.as<u64>();
+                u32* rec_blk = (u32*)(rec_val + (Kcap + 4));
+                if ((rc = e->ms_hist.ensure(((size_t)chunks + 1) * mb * 4 + (size_t)chunks * 4 + 8192))) return rc;
+                u32* hist = e->ms_hist.as<u32>();
+                u32* tot = hist + (size_t)chunks * mb;
+                u32* nrec = tot + mb + 64;
+                FkOut fo{rec_blk, rec_val, nrec, hist, mb, e->mm.as<uint4>(), e->dwork.as<unsigned long long>()};
+                hipLaunchKernelGGL((k_fkeys<V>), dim3(chunks), dim3(FK_THREADS), 0, st, VA, kst, bb, bsum, bbase, nbuckets, gb, newidx, nb, fo,
+                                   std::getenv("KSP_DEBUG_COOP") ? std::max<u32>(KG_COOP, (u32)std::atoi(std::getenv("KSP_DEBUG_COOP"))) : KG_COOP, scal);
+                e->pre_zeroed_work = false;
+                phase_mark(e, st, "block lists");
+                hipLaunchKernelGGL(k_fms_scan, dim3(nb), dim3(256), 0, st, hist, mb, chunks, scal, tot, blk_raw, blk_pos, nb);
+                KSP_HIP(hipMemcpyAsync(e->h_scal, scal, 120, hipMemcpyDeviceToHost, st));   // [0] max key, [1] list words, [2] keys, [6] entries, [9] / [14] overflow (one copy)
+                KSP_HIP(hipEventRecord(e->ev_rb, st));
+                hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
+                if ((rc = e->pmask.ensure((Kcap + (u64)nb * (WIN + 4) + 4 * WIN) * 16))) return rc;
+                const size_t bit_words = (size_t)(((Tt + 63) / 64) * 2 + 2);
+                unsigned char* flags = (unsigned char*)e->tbits.p + bit_words * 4;
+                if (mb == 256)
+                    hipLaunchKernelGGL((k_fms_place<256>), dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, rec_val, nrec, bbase, gb, hist, blk_pos, nb,
+                                       e->bkeys.as<u32>(), e->info.as<u32>(), e->mm.as<uint4>(), e->pmask.as<uint4>(), flags, scal);
+                else
+                    hipLaunchKernelGGL((k_fms_place<1024>), dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, rec_val, nrec, bbase, gb, hist, blk_pos, nb,
+                                       e->bkeys.as<u32>(), e->info.as<u32>(), e->mm.as<uint4>(), e->pmask.as<uint4>(), flags, scal);
+                KSP_HIP(wait_readback(e));
+                if ((seg || seg3_used) && ((u32)e->h_scal[PC_OVF] == 4 || (u32)e->h_scal[PC_OVF] == 5)) {
+                    e->seg_off = true;
+                    e->part_fail = (int)(u32)e->h_scal[PC_OVF];
+                    return build_impl<V>(e, d_keys, d_w, st, phase);
+                }
+                if ((u32)e->h_scal[PC_OVF]) {
+                    e->part_off = true;
+                    e->part_fail = (int)(u32)e->h_scal[PC_OVF];
+                    return build_impl<V>(e, d_keys, d_w, st, phase);
+                }
+                e->max_key = e->h_scal[0];
+                e->have_max_key = true;
+                {
+                    int bits = 1;
+                    while (bits < 64 && (e->max_key >> bits)) ++bits;
+                    e->key_bits = bits;
+                }
+                const char* jm = std::getenv("KSP_JOIN");
+                const bool want_matches = (jm && std::string(jm) == "matches") || (!jm && e->h_scal[6] < 4 * e->h_scal[1]);
+                if ((u32)(e->h_scal[9] >> 32) || (u32)e->h_scal[9] || want_matches) {   // an oversize bucket / sparse sharing: pass by pass from now on
+                    e->fused_off = true;
+                    return build_impl<V>(e, d_keys, d_w, st, phase);
+                }
+                m = e->h_scal[6];
+                e->n_kept = m;
+                if (nw) e->kept_frac = std::max(0.05, (double)m / (double)nw);
+                e->rank1_ok = false;
+                e->fused_used = 1;
+                if (m == 0) return KSP_OK;
+                const u64 K = std::max<u64>(1, e->h_scal[1]);
+                {
+                    const u64 avg = K / nb + 1;
+                    u32 nc = NP;
+                    while ((u64)nc * 32 < 4 * avg && nc < e->ncell) nc <<= 1;
+                    e->ncell = std::min(e->ncell, nc);
+                }
+                hipLaunchKernelGGL(k_cidx, dim3(grid_for((u64)nb * (e->ncell + 1), bs)), dim3(bs), 0, st, e->bkeys.as<u32>(),
+                                   blk_raw, blk_pos, scal, e->part.as<u32>(), nb, e->ncell);
+                KSP_HIP(hipGetLastError());
+                e->pmask_on = true;
+                e->have_dwork = true;
+                e->have_rank_pairs = false;
+                e->fused_flags = true;
+                e->pre_zeroed_bits = false;
+                e->scal_fresh = true;
+                return KSP_OK;
+            }
+        }
         if (!e->hb_slots) {   // persistent workgroups: as many as fit on the device at once
             int per_cu = 0, cus = 0;
             KSP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_bucket_group, HB_THREADS, 0));
@@ -1066,8 +1209,9 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     const size_t bit_words = (size_t)(((T + 63) / 64) * 2 + 2);
     if ((rc = e->tbits.ensure(bit_words * 4 + T + 64))) return rc;   // packed bitmap, then one flag byte per tile
     if ((rc = e->dwork.ensure(((size_t)nb + 2) * 8))) return rc;
+    const bool fused = e->fused_flags;        // the bucket-resident build wrote the tile flags and the diagonal work with its lists
     const bool ranked = e->have_rank_pairs;   // the key-by-key build left the pairs in rank order: nothing to sort
-    if (!ranked) {
+    if (!ranked && !fused) {
         if ((rc = e->KA.ensure((K + 4) * 8))) return rc;
         if ((rc = e->KB.ensure((K + 4) * 8))) return rc;
     }
@@ -1076,16 +1220,16 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     u32 *pr2 = ranked ? e->gp.as<u32>() + 3 * e->gp_stride : (u32*)e->KB.p, *pb2 = ranked ? e->gp.as<u32>() + 2 * e->gp_stride : pr2 + (K + 4);
     unsigned char* flags = (unsigned char*)e->tbits.p + bit_words * 4;
     phase_mark(e, st, "work list");
-    if (!e->pre_zeroed_bits) KSP_HIP(hipMemsetAsync(e->tbits.p, 0, bit_words * 4 + T + 64, st));
+    if (!e->pre_zeroed_bits && !fused) KSP_HIP(hipMemsetAsync(e->tbits.p, 0, bit_words * 4 + T + 64, st));
     e->pre_zeroed_bits = false;
-    if (!(ranked && e->have_dwork)) {
+    if (!fused && !(ranked && e->have_dwork)) {
         KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
         const u32 shares = (u32)std::min<u64>(64, std::max<u64>(1, 2048 / nb));
         hipLaunchKernelGGL(k_list_pairs, dim3(nb, shares), dim3(256), 0, st, e->bkeys.as<u32>(), e->info.as<u32>(),
                            e->mm.as<uint4>(), e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), pr, pb,
                            e->dwork.as<unsigned long long>());
     }
-    if (!ranked) {
+    if (!ranked && !fused) {
         int rbits = 1;
         while (rbits < 32 && (U >> rbits)) ++rbits;
         size_t tb = 0;
@@ -1093,7 +1237,7 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
         if ((rc = e->tmp.ensure(tb))) return rc;
         KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, pr, pr2, pb, pb2, (size_t)K, 0, rbits, st));
     }
-    hipLaunchKernelGGL(k_tile_flags, dim3(grid_for(K, 256)), dim3(256), 0, st, pr2, pb2, K, nb, flags);
+    if (!fused) hipLaunchKernelGGL(k_tile_flags, dim3(grid_for(K, 256)), dim3(256), 0, st, pr2, pb2, K, nb, flags);
     hipLaunchKernelGGL(k_pack_flags, dim3(grid_for(T, 256)), dim3(256), 0, st, flags, T, e->tbits.as<u32>());
     // match records for the join (sparse sharing: few holders per list word — the lists are long and a block pair
     // matches next to nothing of them; KSP_JOIN=matches / search forces the choice)
@@ -1232,6 +1376,9 @@ static int build_schedule(ksp_engine* e) {
     e->collect = false;
     e->act_tid.clear(); e->act_rec.clear();
     e->st.n_active_tiles = e->st.n_tiles;
+    e->st.n_join_workgroups = e->st.n_tiles;   // (dense mode: one workgroup per tile)
+    e->st.n_kept_entries = e->n_kept;
+    e->st.n_kept_keys = e->h_scal_keys;
     if (!e->have_bits) return KSP_OK;
     const u32 nb = e->nb;
     const u64 T = (u64)nb * (nb + 1) / 2;
@@ -1520,6 +1667,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     e->st.sort_bits = e->sort_bits;
     e->st.partition_kind = e->sort_entries ? e->part_kind : 0;
     e->st.partition_fallback = e->part_fail;
+    e->st.stage1_kind = e->fused_used;
     if (e->sort_entries) KSP_HIP(hipEventElapsedTime(&e->st.ms_sort, e->ev[4], e->ev[5]));
     return KSP_OK;
 }
@@ -2210,21 +2358,6 @@ static int sort_edges_device(ksp_edge* d_edges, u64 n, u32 n_sources) {
 }
 
 namespace {
-// a plain barrier for the per-device host threads (C++17: no std::barrier)
-struct HostBarrier {
-    std::mutex mu;
-    std::condition_variable cv;
-    int n, waiting = 0;
-    unsigned gen = 0;
-    explicit HostBarrier(int n_) : n(n_) {}
-    void wait() {
-        std::unique_lock<std::mutex> l(mu);
-        const unsigned g = gen;
-        if (++waiting == n) { waiting = 0; ++gen; cv.notify_all(); }
-        else cv.wait(l, [&] { return gen != g; });
-    }
-};
-
 struct MultiJob {
     // input (host): sketches (keys / weights / offsets) or an inverted index (key_off / sources / key_weights)
     const u64* keys = nullptr; const u32* weights = nullptr; const u64* offsets = nullptr;
@@ -2276,8 +2409,7 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
         std::string err;
     };
     std::vector<Dev> dev((size_t)nd);
-    HostBarrier bar(nd);
-    std::atomic<int> failed{0};
+    FailBarrier bar(nd);   // (the failure decision is latched once per barrier generation: host_sync.h)
     std::vector<u32> lab_min;                 // MIN-combined labels (host)
     std::vector<std::vector<u32>> lab_dev((size_t)nd);
     std::vector<u64> all_sizes((size_t)nd * 4, 0);
@@ -2288,8 +2420,8 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
     auto body = [&](int i) {
         Dev& D = dev[(size_t)i];
         const int device = devices[i];
-        auto fail = [&](int rc) { D.rc = rc; D.err = g_error; failed.store(1); };
-        auto sync_point = [&]() { bar.wait(); return failed.load() != 0; };
+        auto fail = [&](int rc) { D.rc = rc; D.err = g_error; bar.fail(); };
+        auto sync_point = [&]() { return bar.sync(); };
         int rc = ksp_engine_create(device, &D.e);
         if (rc) fail(rc);
         for (int j = 0; j < nd && !rc; ++j)   // direct xGMI copies between the devices of this job (already enabled: fine)
@@ -2298,7 +2430,7 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
         int owner = i;   // the first worker on my device uploads the input; the others use its copy
         for (int j = 0; j < i; ++j)
             if (devices[j] == device) { owner = j; break; }
-        if (!failed.load() && n && owner == i) {
+        if (!bar.failed_hint() && n && owner == i) {
             if (job.postings) {
                 if ((rc = ksp_device_malloc(device, n * 4, &D.d_a)) || (rc = ksp_memcpy_h2d(D.d_a, job.sources, n * 4))) fail(rc);
                 if (!rc && job.key_weights &&
@@ -2312,7 +2444,7 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
         }
         if (nd > 1 && sync_point()) return;   // (the uploads are complete: ksp_memcpy_h2d is synchronous)
         if (owner != i) { D.d_a = dev[(size_t)owner].d_a; D.d_b = dev[(size_t)owner].d_b; D.borrowed = true; }
-        if (!failed.load()) {
+        if (!bar.failed_hint()) {
             if (job.postings)
                 rc = ksp_engine_build_postings(D.e, job.key_off, (const u32*)D.d_a, (const u32*)D.d_b, job.n_keys, N, nullptr);
             else if (nd == 1)
@@ -2323,7 +2455,7 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
         }
         if (!job.postings && nd > 1) {   // the slices become the full lists on every device
             // common source order: element-wise MIN of the devices' labels
-            if (!failed.load() && N) {
+            if (!bar.failed_hint() && N) {
                 lab_dev[(size_t)i].resize(N);
                 if ((rc = D.labels.ensure((size_t)N * 4)) || (rc = ksp_engine_slice_labels(D.e, D.labels.as<u32>(), nullptr)) ||
                     (rc = ksp_memcpy_d2h(lab_dev[(size_t)i].data(), D.labels.p, (u64)N * 4)))
@@ -2340,7 +2472,7 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
                 fail(rc);
             else if (!N && (rc = ksp_engine_slice_finish(D.e, nullptr, nullptr)))
                 fail(rc);
-            if (!failed.load() && (rc = ksp_engine_slice_sizes(D.e, D.sizes))) fail(rc);
+            if (!bar.failed_hint() && (rc = ksp_engine_slice_sizes(D.e, D.sizes))) fail(rc);
             for (int q = 0; q < 4; ++q) all_sizes[(size_t)i * 4 + q] = D.sizes[q];
             if (sync_point()) return;
             // every device receives every slice: [part][stride] buffers, filled by peer copies from the owners
@@ -2354,12 +2486,12 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
                 if ((rc = D.exp[q].ensure(bytes[q])) || (rc = D.gather[q].ensure(bytes[q] * (size_t)nd))) fail(rc);
                 else if (hipMemset(D.exp[q].p, 0, bytes[q]) != hipSuccess || hipMemset(D.gather[q].p, 0, bytes[q] * (size_t)nd) != hipSuccess) { set_error("pairwise: hipMemset"); fail(rc = KSP_E_HIP); }
             }
-            if (!failed.load() && n &&
+            if (!bar.failed_hint() && n &&
                 (rc = ksp_engine_slice_export(D.e, D.exp[0].as<u32>(), D.exp[1].as<u32>(), weighted ? D.exp[2].as<u32>() : nullptr,
                                               D.exp[3].as<u32>(), D.exp[4].as<u32>(), D.exp[5].p, nullptr)))
                 fail(rc);
             if (sync_point()) return;
-            for (int j = 0; j < nd && !failed.load(); ++j)      // my slice into device j's gather buffers
+            for (int j = 0; j < nd && !bar.failed_hint(); ++j)      // my slice into device j's gather buffers
                 for (int q = 0; q < 6; ++q) {
                     if (!bytes[q]) continue;
                     if (hipMemcpyPeer((char*)dev[(size_t)j].gather[q].p + bytes[q] * (size_t)i, devices[j], D.exp[q].p, device, bytes[q]) != hipSuccess) {

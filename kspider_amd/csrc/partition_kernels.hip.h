@@ -131,6 +131,16 @@ __device__ inline void part_reserve(const PartLists& pl, const u32 L, const u32 
     g1 = q1 == q0 ? g0 : part_wait_page(pl.pt, L * pl.ptw, q1, pl.ptw, ovf);
 }
 
+// The overflow word as ONE decision per workgroup.  Other workgroups of the same launch raise it while this one runs;
+// waves that read it on their own could disagree, and barriers skip exited waves — the survivors would go on with LDS
+// the exited waves never wrote (addresses among it).  Thread 0 reads, everybody branches on the copy in LDS.
+__device__ inline bool part_ovf_uniform(const u32* __restrict__ ovf) {
+    __shared__ u32 s_ovf_seen;
+    if (threadIdx.x == 0) s_ovf_seen = __hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return s_ovf_seen != 0;
+}
+
 // source of the first entry of every chunk (tbl[nchunks] = the last source): the bisection is done once, by a
 // kernel of its own, instead of sitting at the start of every chunk's critical path
 __global__ void k_part_src(const u64* __restrict__ off, const u32 n_sources, const u32 nchunks, u32* __restrict__ tbl,
@@ -402,7 +412,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_part_mid(const u64* __restrict__
     __shared__ u32 s_ls[256], s_cnt[256], s_v[256], s_g0[256], s_g1[256];
     const u32 ow = pa.owner[blockIdx.x];
     u32* const ovf = const_cast<u32*>(reinterpret_cast<const u32*>(scal + PC_OVF));
-    if (!ow || *ovf) return;
+    if (part_ovf_uniform(ovf) || !ow) return;
     const u32 L = (ow - 1) / pa.ptw, q = (ow - 1) % pa.ptw, len = pa.cursors[(size_t)L * P1_LINE];
     if (len <= (q << P1_PLOG)) return;
     const u32 m = min(P1_PAGE, len - (q << P1_PLOG));
@@ -622,7 +632,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
     __shared__ u32 s_pre[SEG_SMAX + 1], s_addr[SEG_SMAX];
     __shared__ u32 s_w[P2_THREADS / 64];
     u32* const ovf = reinterpret_cast<u32*>(scal + PC_OVF);
-    if (*ovf) return;
+    if (part_ovf_uniform(ovf)) return;
     const u32 g = blockIdx.x / nb1, B = blockIdx.x % nb1;   // (consecutive workgroups read neighbouring segments of the same sources)
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 s0 = groups[g], ns = groups[g + 1] - s0;        // (<= SEG_SMAX by construction)
@@ -738,7 +748,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_mid(const u64* __restrict__ 
     __shared__ u32 s_pre[SEG_SMAX + 1], s_addr[SEG_SMAX];
     __shared__ u32 s_w[P2_THREADS / 64];
     u32* const ovf = reinterpret_cast<u32*>(scal + PC_OVF);
-    if (*ovf) return;
+    if (part_ovf_uniform(ovf)) return;
     const u32 g = blockIdx.x / nb1, BA = blockIdx.x % nb1;
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 s0 = groups[g], ns = groups[g + 1] - s0;        // (<= SEG_SMAX by construction)

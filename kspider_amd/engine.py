@@ -46,6 +46,7 @@ class Stats(ctypes.Structure):
         ("partition_kind", ctypes.c_int), ("partition_fallback", ctypes.c_int),
         ("n_match_records", ctypes.c_uint64), ("n_join_workgroups", ctypes.c_uint64),
         ("n_kept_entries", ctypes.c_uint64), ("n_kept_keys", ctypes.c_uint64),
+        ("stage1_kind", ctypes.c_int), ("reserved_", ctypes.c_int),
     ]
 
     def as_dict(self):

@@ -88,13 +88,46 @@ void read_raw_table(Reader& r, size_t slot_bytes, int kwidth, bool trailer, Fn f
 // PAIRS_COUNTER restatement (src/pairwise.cpp:22-27): 4096 submaps, one
 // std::mutex each, key pair<u32,u32>, value u64.
 // ---------------------------------------------------------------------------
-struct PairHash {
-    size_t operator()(const std::pair<uint32_t, uint32_t>& p) const {
-        // boost::hash_combine shape (only decides bucket/iteration order)
-        size_t seed = 0;
-        seed ^= (size_t)p.first + 0x9e3779b9 + (seed << 6) + (seed >> 2);
-        seed ^= (size_t)p.second + 0x9e3779b9 + (seed << 6) + (seed >> 2);
-        return seed;
+// Open-addressing table, u64 key -> u64 value: power-of-two capacity, linear probing, grown at a load of 7/8 —
+// the container CLASS of phmap's flat maps (one contiguous slot array, no per-node allocation), without its
+// SSE control-byte groups.  Not an algorithmic improvement over the reference: same updates, same locking.
+// (Round 2 used node-based std::unordered_map here, which BASELINE.md section 2 did not describe.)
+struct FlatMap {
+    static constexpr uint64_t kEmpty = ~0ull;   // (no pair (2^32-1, 2^32-1): source_1 < source_2; no colour key 2^64-1)
+    std::vector<uint64_t> keys, vals;
+    size_t used = 0, mask = 0;
+    static uint64_t mix(uint64_t h) {   // phmap mixes the user's hash before use (128-bit multiply, folded)
+        const unsigned __int128 m = (unsigned __int128)h * 0xde5fb9d2630458e9ull;
+        return (uint64_t)m + (uint64_t)(m >> 64);
+    }
+    void grow() {
+        const size_t cap = keys.empty() ? 16 : keys.size() * 2;
+        std::vector<uint64_t> k(cap, kEmpty), v(cap, 0);
+        for (size_t i = 0; i < keys.size(); ++i)
+            if (keys[i] != kEmpty) {
+                size_t j = (size_t)(mix(keys[i]) >> 12) & (cap - 1);
+                while (k[j] != kEmpty) j = (j + 1) & (cap - 1);
+                k[j] = keys[i];
+                v[j] = vals[i];
+            }
+        keys.swap(k);
+        vals.swap(v);
+        mask = cap - 1;
+    }
+    // value slot of `key`, inserted with `init` when absent (`mixed` = mix(key), computed once by the caller)
+    uint64_t& at(uint64_t key, uint64_t mixed, uint64_t init, bool& fresh) {
+        if ((used + 1) * 8 > keys.size() * 7) grow();
+        size_t j = (size_t)(mixed >> 12) & mask;
+        while (keys[j] != kEmpty && keys[j] != key) j = (j + 1) & mask;
+        fresh = keys[j] == kEmpty;
+        if (fresh) { keys[j] = key; vals[j] = init; ++used; }
+        return vals[j];
+    }
+    const uint64_t* find(uint64_t key) const {
+        if (keys.empty()) return nullptr;
+        size_t j = (size_t)(mix(key) >> 12) & mask;
+        while (keys[j] != kEmpty && keys[j] != key) j = (j + 1) & mask;
+        return keys[j] == kEmpty ? nullptr : &vals[j];
     }
 };
 
@@ -102,22 +135,28 @@ struct ShardedPairs {
     static constexpr int kShards = 4096;  // N = 12
     struct Shard {
         std::mutex mu;
-        std::unordered_map<std::pair<uint32_t, uint32_t>, uint64_t, PairHash> m;
+        FlatMap m;   // key = source_1 << 32 | source_2
     };
     std::vector<Shard> shards{(size_t)kShards};
     // try_emplace_l(key, [c](v){ v.second += c; }, c)   (src/pairwise.cpp:221-225)
     void add(const std::pair<uint32_t, uint32_t>& k, uint32_t c) {
-        size_t h = PairHash()(k);
-        Shard& s = shards[(h ^ (h >> 12)) & (kShards - 1)];
+        const uint64_t key = ((uint64_t)k.first << 32) | k.second;
+        const uint64_t h = FlatMap::mix(key);   // (boost::hash<pair> in the reference: decides shard and slot only)
+        Shard& s = shards[h & (kShards - 1)];   // the low 12 bits pick the submap, the bits above them the slot
         std::lock_guard<std::mutex> g(s.mu);
-        auto it = s.m.find(k);
-        if (it != s.m.end()) it->second += c;
-        else s.m.emplace(k, (uint64_t)c);
+        bool fresh;
+        uint64_t& v = s.m.at(key, h, (uint64_t)c, fresh);
+        if (!fresh) v += c;
     }
     uint64_t size() const {
         uint64_t n = 0;
-        for (auto& s : shards) n += s.m.size();
+        for (auto& s : shards) n += s.m.used;
         return n;
+    }
+    template <class Fn> void for_each(Fn fn) const {   // fn(source_1, source_2, shared), table order
+        for (auto& s : shards)
+            for (size_t i = 0; i < s.m.keys.size(); ++i)
+                if (s.m.keys[i] != FlatMap::kEmpty) fn((uint32_t)(s.m.keys[i] >> 32), (uint32_t)s.m.keys[i], s.m.vals[i]);
     }
 };
 
@@ -135,7 +174,7 @@ struct Index {
     // color_to_ids after insert_or_assign with the colour narrowed to uint32
     // (src/pairwise.cpp:103,109); kept in first-insertion order.
     std::vector<std::pair<uint32_t, std::vector<uint32_t>>> colors;
-    std::unordered_map<uint32_t, uint32_t> colors_count;            // :113-121 (both narrowed)
+    FlatMap colors_count;                                           // :113-121 int_int_map: flat, both narrowed to 32 bits
     std::vector<std::pair<uint32_t, uint32_t>> kmer_count_slots;    // slot order (:175-179)
     std::unordered_map<uint32_t, uint32_t> kmer_count;
 };
@@ -170,9 +209,10 @@ void load_index(const std::string& prefix, int kwidth, bool trailer, Index& ix) 
             uint64_t k, v;
             std::memcpy(&k, s, 8);
             std::memcpy(&v, s + 8, 8);
-            ix.colors_count[(uint32_t)k] = (uint32_t)v;
+            bool fresh;
+            ix.colors_count.at((uint32_t)k, FlatMap::mix((uint32_t)k), 0, fresh) = (uint32_t)v;
         });
-        if (ix.colors_count.empty()) throw std::runtime_error("oracle: empty color_count (assert :117)");
+        if (!ix.colors_count.used) throw std::runtime_error("oracle: empty color_count (assert :117)");
     }
     {   // groupID_to_kmerCount (:166-170)
         Reader r(prefix + "_groupID_to_kmerCount.bin");
@@ -205,8 +245,7 @@ double accumulate(Index& ix, int user_threads, ShardedPairs& edges) {
                 uint32_t s2 = item.second[seq_pair.second];
                 if (s1 > s2) std::swap(s1, s2);  // ascending() :73-78
                 uint32_t ccount = 0;             // colorsCount[item.first] (:221), 0 when absent
-                auto it = ix.colors_count.find(item.first);
-                if (it != ix.colors_count.end()) ccount = it->second;
+                if (const uint64_t* cc = ix.colors_count.find(item.first)) ccount = (uint32_t)*cc;
                 edges.add(std::make_pair(s1, s2), ccount);
             }
         }
@@ -229,8 +268,7 @@ void write_outputs(const std::string& prefix, Index& ix, ShardedPairs& edges, bo
         for (auto& it : ix.kmer_count_slots) f << ++counter << '\t' << it.first << '\t' << it.second << '\n';
     }
     std::vector<std::pair<std::pair<uint32_t, uint32_t>, uint64_t>> rows;
-    for (auto& s : edges.shards)
-        for (auto& e : s.m) rows.push_back(e);
+    edges.for_each([&](uint32_t a, uint32_t b, uint64_t v) { rows.push_back({{a, b}, v}); });
     if (sorted) std::sort(rows.begin(), rows.end());
     std::ofstream myfile(prefix + "_kSpider_pairwise.tsv");
     myfile << "source_1"
@@ -300,7 +338,8 @@ int oracle_accumulate_mem(const uint32_t* color_off, const uint32_t* sources, co
             std::vector<uint32_t> v(sources + color_off[c], sources + color_off[c + 1]);
             upd += (uint64_t)v.size() * (v.size() - 1) / 2;
             ix.colors.emplace_back(c + 1, std::move(v));
-            ix.colors_count[c + 1] = color_w[c];
+            bool fresh;
+            ix.colors_count.at(c + 1, FlatMap::mix(c + 1), 0, fresh) = color_w[c];
         }
         ShardedPairs edges;
         double secs = accumulate(ix, user_threads, edges);
@@ -311,8 +350,7 @@ int oracle_accumulate_mem(const uint32_t* color_off, const uint32_t* sources, co
         if (out_edges) {
             if (ne > out_capacity) throw std::runtime_error("oracle: edge buffer too small");
             uint64_t i = 0;
-            for (auto& s : edges.shards)
-                for (auto& e : s.m) out_edges[i++] = oracle_edge{e.first.first, e.first.second, e.second};
+            edges.for_each([&](uint32_t a, uint32_t b, uint64_t v) { out_edges[i++] = oracle_edge{a, b, v}; });
             std::sort(out_edges, out_edges + ne, [](const oracle_edge& a, const oracle_edge& b) {
                 return a.source_1 != b.source_1 ? a.source_1 < b.source_1 : a.source_2 < b.source_2;
             });

@@ -182,3 +182,15 @@ def test_malformed_signature_and_bin_corpus(exe, oracle_lib, tmp_path):
         (d / "b.bin").write_bytes(data)
         rc, line, _ = _run(exe, "bins", str(d), str(tmp_path / ("bins_" + name)))
         assert rc == KSP_E_IO, (name, line)
+
+
+def test_multi_device_barrier_returns_on_an_injected_failure_at_every_stage(exe):
+    """run_multi's host threads (one per device; kspider_amd/csrc/engine.hip) meet at ksp::FailBarrier sync points.  A
+    failure injected into any worker at any of the 12 stages must make EVERY worker return at the sync point behind
+    that stage — none left waiting at a later barrier (the round-2 race: a flag read after leaving a plain barrier).
+    ThreadSanitizer build; a watchdog inside the program turns a hang into exit code 3."""
+    check = os.path.join(os.path.dirname(exe), "host_sync_check")
+    p = subprocess.run([check, "12"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    assert "ThreadSanitizer" not in p.stderr, p.stderr[-3000:]
+    assert "host_sync ok" in p.stdout, p.stdout
