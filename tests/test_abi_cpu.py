@@ -38,7 +38,7 @@ def test_cxx_symbol_of_reference_signature_is_exported():
 
 def test_struct_layouts():
     assert engine.EDGE_DTYPE.itemsize == 16
-    assert ctypes.sizeof(engine.Stats) == 9 * 8 + 4 * 4 + 2 * 8 + 8 + 4 * 4 + 4 * 8  # (= sizeof(ksp_stats), include/kspider_amd.h)
+    assert ctypes.sizeof(engine.Stats) == 9 * 8 + 4 * 4 + 2 * 8 + 8 + 4 * 4 + 4 * 8 + 2 * 4  # (= sizeof(ksp_stats), include/kspider_amd.h)
 
 
 def test_missing_index_fails_loudly(tmp_path):
