@@ -425,6 +425,10 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     if (hand && nb_hand <= 65536 && !e->seg_off && e->h_off.size() == (size_t)N + 1 && N) {
         const char* sv = std::getenv("KSP_SEG");   // 0: never, 1: whatever the segment length (diagnostic / tests)
         while (((nb_hand + (1u << seg_pb2) - 1) >> seg_pb2) > 256) ++seg_pb2;
+        // (fewer, longer segments — 256 final buckets per range, C2: 51 entries per segment instead of 26 — were measured with
+        //  the vectorised boundary pass: partition 0.42 -> 0.44 ms, the shorter write runs cost more than the longer reads save)
+        const int pb2_min = seg_pb2;
+        if (const char* pv = std::getenv("KSP_DEBUG_SEG_PB2")) seg_pb2 = std::min(8, std::max(pb2_min, std::atoi(pv)));   // (timing experiments)
         seg_nb1 = (nb_hand + (1u << seg_pb2) - 1) >> seg_pb2;
         const u64 mean_seg = n / N / seg_nb1;
         seg = (sv ? std::atoi(sv) != 0 : mean_seg >= SEG_MIN_LEN && seg_runs_fit(seg_nb1));
@@ -743,7 +747,9 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         // ---- the bucket-resident middle of stage 1 (fused_kernels.hip.h): grouping + emit + labels in one kernel, the
         // group records straight to rank order, one read-back.  Unweighted whole builds on the hand-written partition
         // whose blocks fit the split's tables; anything it cannot take (an oversize bucket, sparse sharing) sets
-        // fused_off and the build is repeated pass by pass (KSP_FUSED=0 forces that: tests run both).
+        // fused_off and the build is repeated pass by pass.  Measured on C2 (round 3): correct, 0.6 GB less HBM traffic per
+        // step, but 0.14 ms SLOWER than the pass-by-pass kernels (bucket-at-a-time kernels are bound by LDS latency and
+        // barriers, not by HBM: DESIGN.md section 5) — so it only runs when KSP_FUSED=1 asks for it (tests run both).
         e->fused_flags = false;
         e->fused_used = 0;
         if constexpr (!W) {
@@ -752,11 +758,11 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             const u32 ms_max = (msv && std::atoi(msv) == 1024) ? MS_MAXB : 256u;
             const u64 Tt = (u64)nb * (nb + 1) / 2;
             if (hand && phase == 0 && reorder && nb <= ms_max && nb <= FK_NB_MAX && Tt <= (1ull << 22) && !e->fused_off && !e->key_groups_off &&
-                !(fv && std::atoi(fv) == 0) && !(msv && std::atoi(msv) == 0) && e->pre_zeroed_bits && e->pre_zeroed_work) {
+                (fv && std::atoi(fv) == 1) && !(msv && std::atoi(msv) == 0) && e->pre_zeroed_bits && e->pre_zeroed_work) {
                 if ((rc = e->biglist.ensure(((size_t)nbuckets + 1) * 4))) return rc;
                 if ((rc = e->VA.ensure((nslots + 4) * sizeof(V)))) return rc;
                 if ((rc = e->FK.ensure((nslots / 2 + (u64)nbuckets + 16) * 4))) return rc;
-                if ((rc = e->mm.ensure((nslots / (INLINE_MAX + 1) + 16) * 16))) return rc;
+                if ((rc = e->mm.ensure((nw / (INLINE_MAX + 1) + 16) * 16))) return rc;   // (a mask per 5 kept entries at most)
                 VA = e->VA.as<V>();
                 u32* kst = (u32*)e->FK.p;
                 if (!e->hb_slots) {
@@ -798,7 +804,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                 // the (block, key) groups, chunk by chunk, straight into rank order
                 phase_mark(e, st, "key groups");
                 u32 gb = 8;
-                if (const char* gv = std::getenv("KSP_DEBUG_FK_GB")) gb = (u32)std::max(1, std::atoi(gv));   // (timing experiments)
+                if (const char* gv = std::getenv("KSP_DEBUG_FK_GB")) gb = (u32)std::min<int>(FK_GBMAX, std::max(1, std::atoi(gv)));   // (timing experiments)
                 const u32 chunks = grid_for(nbuckets, gb);
                 const u32 mb = nb <= 256 ? 256u : 1024u;
                 const u64 Kcap = nw;   // records <= kept entries <= entries
@@ -810,9 +816,11 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                 u32* hist = e->ms_hist.as<u32>();
                 u32* tot = hist + (size_t)chunks * mb;
                 u32* nrec = tot + mb + 64;
-                FkOut fo{rec_blk, rec_val, nrec, hist, mb, e->mm.as<uint4>(), e->dwork.as<unsigned long long>()};
-                hipLaunchKernelGGL((k_fkeys<V>), dim3(chunks), dim3(FK_THREADS), 0, st, VA, kst, bb, bsum, bbase, nbuckets, gb, newidx, nb, fo,
-                                   std::getenv("KSP_DEBUG_COOP") ? std::max<u32>(KG_COOP, (u32)std::atoi(std::getenv("KSP_DEBUG_COOP"))) : KG_COOP, scal);
+                FkOut fo{rec_blk, rec_val, nrec, hist, e->mm.as<uint4>(), e->dwork.as<unsigned long long>()};
+                if (mb == 256)
+                    hipLaunchKernelGGL((k_fkeys<V, 256>), dim3(chunks), dim3(FK_THREADS), 0, st, VA, kst, bb, bsum, bbase, nbuckets, gb, newidx, N, nb, fo, scal);
+                else
+                    hipLaunchKernelGGL((k_fkeys<V, 1024>), dim3(chunks), dim3(FK_THREADS), 0, st, VA, kst, bb, bsum, bbase, nbuckets, gb, newidx, N, nb, fo, scal);
                 e->pre_zeroed_work = false;
                 phase_mark(e, st, "block lists");
                 hipLaunchKernelGGL(k_fms_scan, dim3(nb), dim3(256), 0, st, hist, mb, chunks, scal, tot, blk_raw, blk_pos, nb);
@@ -2573,6 +2581,15 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
     if (rc && *out_edges) { ksp_free(*out_edges); *out_edges = nullptr; *n_edges = 0; }
     return rc;
 }
+
+#ifdef KSP_FKTIME
+int ksp_debug_fktime(unsigned long long* out16, int reset) {
+    KSP_HIP(hipDeviceSynchronize());
+    KSP_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(ksp::fk_time), 16 * 8));
+    if (reset) { unsigned long long z[16] = {0}; KSP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ksp::fk_time), z, 16 * 8)); }
+    return KSP_OK;
+}
+#endif
 
 int ksp_pairwise_host_multi(const uint64_t* keys, const uint32_t* weights, const uint64_t* offsets, uint32_t n_sources,
                             const int* devices, int n_devices, ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats) {

@@ -24,7 +24,7 @@
 // src/pairwise.cpp:194-225 equivalent: still "bring the holders of every key together", nothing else.
 #pragma once
 
-constexpr u32 FK_THREADS = 256;
+constexpr u32 FK_THREADS = 512;
 constexpr u32 FK_CAP = HB_CAP;          // kept holders of one bucket staged at a time
 constexpr u32 FK_KEYS = HB_CAP / 2;     // kept keys of one bucket
 constexpr u32 FK_NB_MAX = 1024;         // blocks the LDS tables of k_fkeys hold (= MS_MAXB: the split's tables)
@@ -56,9 +56,21 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_fgroup(const u64* __restrict_
     constexpr u32 PER = (HB_SLOTS + 1 + NT - 1) / NT;
     const u32 tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
+    // (the bounds through restrict pointers: nothing this kernel writes overlaps them, so the next bucket's bounds are scalar
+    //  loads — as vector loads each was waited for on the spot, three round trips at the head of every pass)
+    const u32* __restrict__ const bstart = bb.start;
+    const u32* __restrict__ const bcnt = bb.cnt;
+    const u32 bcap = bb.cap;
+    auto bfirst = [&](const u32 q) { return bcap ? q * bcap : bstart[q]; };
+    auto bsize = [&](const u32 q) { return bcap ? min(bcnt[q], bcap) : bstart[q + 1] - bstart[q]; };
+    // bounds two buckets ahead: the loads of bucket b + 2 x grid are issued at the head of pass b and first looked at when
+    // pass b ends (next bucket's keys are fetched from bounds that arrived a whole pass earlier)
+    u32 vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     u32 b = blockIdx.x;
-    u32 b0 = 0, raw = 0;
-    if (b < nbuckets) { b0 = bb.first(b); raw = bb.size(b); }
+    u32 b0 = 0, raw = 0, n0 = 0, nraw = 0;
+    if (b < nbuckets) { b0 = bfirst(b); raw = bsize(b); }
+    if (b + gridDim.x < nbuckets) { n0 = bfirst(b + gridDim.x); nraw = bsize(b + gridDim.x); }
     u32 size = raw > HB_CAP ? 0 : raw;   // a bucket that does not fit is listed (overflow[1] counts them): the caller falls back
     unsigned long long mykey[EPT], nkey[EPT];
     V mytag[EPT], ntag[EPT];
@@ -68,14 +80,23 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_fgroup(const u64* __restrict_
         mykey[j] = in ? keys[b0 + tid + j * NT] : 0;
         mytag[j] = in ? tags[b0 + tid + j * NT] : V(0);
     }
+    // (the first bucket's loads have landed before the loop is entered: otherwise the compiler's wait-count bookkeeping carries
+    //  "a load may still be writing these registers" into EVERY pass of the loop and drains the memory pipeline — s_waitcnt
+    //  vmcnt(0), the prefetch of the next bucket and every store included — wherever one of them is touched)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
     while (b < nbuckets) {
         if (raw > HB_CAP && tid == 0) {
             const u32 q = atomicAdd(&overflow[1], 1u);
             big_list[q] = b;   // (one slot per bucket: cannot overflow)
         }
-        const u32 bn = b + gridDim.x;
-        u32 n0 = 0, nraw = 0;           // bounds of the next bucket
-        if (bn < nbuckets) { n0 = bb.first(bn); nraw = bb.size(bn); }
+        const u32 bn = b + gridDim.x, bnn = bn + gridDim.x;
+        // bounds of the bucket after the next, loaded through a lane-private zero: the compiler cannot tell that the address is
+        // uniform, so the values stay in vector registers (no readfirstlane, no wait) until the pass ends
+        u32 la = 0, lb = 0;   // (the words as loaded; first / size are worked out when the pass ends)
+        if (bnn < nbuckets) {
+            if (bcap) la = bcnt[bnn + vzero];
+            else { la = bstart[bnn + vzero]; lb = bstart[bnn + 1 + vzero]; }
+        }
         const u32 slots = size <= 416 ? 512u : size <= 832 ? 1024u : size <= 1664 ? 2048u : HB_SLOTS;
         for (u32 i = tid; i <= slots; i += NT) tkey[i] = EMPTY;
         for (u32 i = tid; i <= slots / 2; i += NT) tcnt2[i] = 0;
@@ -157,7 +178,9 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_fgroup(const u64* __restrict_
         const u32 kb0 = fk_kst_first(b0, b);
         for (u32 r = tid; r <= nkeys; r += NT) kst[kb0 + r] = b0 + kst_l[r];
         if (label) {
-            // label pass on the bucket in LDS: one key in (skip + 1), one thread per sampled key (see k_label)
+            // label pass on the bucket in LDS: one key in (skip + 1), one thread per sampled key (see k_label).  No look at
+            // the label first: a load would put a memory round trip per holder on the bucket's critical path — the atomics
+            // are sent without waiting for anything (nothing is returned) and land while the next bucket is grouped.
             for (u32 r = tid * (skip + 1); r < nkeys; r += NT * (skip + 1)) {
                 const u32 f0 = kst_l[r], f1 = kst_l[r + 1];
                 if (f1 - f0 > max_holders) continue;
@@ -165,11 +188,16 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_fgroup(const u64* __restrict_
                 for (u32 x = f0; x < f1; ++x) mn = min(mn, src_of_tag(tag_of(o_tag[x])));
                 for (u32 x = f0; x < f1; ++x) {
                     const u32 s = src_of_tag(tag_of(o_tag[x]));
-                    if (mn < label[(size_t)s << lshift]) atomicMin(&label[(size_t)s << lshift], mn);
+                    if (s != mn) __hip_atomic_fetch_min(&label[(size_t)s << lshift], mn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
         b = bn; b0 = n0; raw = nraw; size = nsize;
+        {
+            const u32 ua = __builtin_amdgcn_readfirstlane(la), ub = __builtin_amdgcn_readfirstlane(lb);
+            n0 = bnn < nbuckets ? (bcap ? bnn * bcap : ua) : 0u;
+            nraw = bnn < nbuckets ? (bcap ? min(ua, bcap) : ub - ua) : 0u;
+        }
 #pragma unroll
         for (u32 j = 0; j < EPT; ++j) { mykey[j] = nkey[j]; mytag[j] = ntag[j]; }
         __syncthreads();   // the table is rebuilt from here on
@@ -187,62 +215,82 @@ __global__ void k_ftotals(const u64* __restrict__ bsum, const u64* __restrict__ 
 
 // ---- (block, key) groups of a chunk of buckets, records straight to rank order -----------------------------------
 // rec_blk / rec_val: region of chunk c starts at place (u32)bbase[first bucket of c]; nrec[c] records are used.
-// hist (MB > 0): records of chunk c per block, row c.  work (nb <= KG_WORK): diagonal work per block, holders in slot nb.
-// ovf[0] is raised when a key cannot be taken (more than FK_CAP holders cannot happen here: a bucket holds at most HB_CAP
-// entries — the caller only runs this kernel when no bucket was oversize).
+// hist: records of chunk c per block, row c (NBT words).  work: diagonal work per block, holders in slot nb.
+// A bucket holds at most HB_CAP entries here (the caller only runs this path when no bucket was oversize).
+//
+// One bucket at a time per workgroup, its successor's tags (-> new source indices) and key starts already in flight:
+//   A  the holders' new indices and the key starts go to LDS; every key marks its first place in a bitmap;
+//   B  prefix popcounts of the bitmap: entry i belongs to key (heads at or below i) - 1;
+//   C  ENTRY-parallel: every holder ORs its bit into its key's 128-bit mask in LDS and compares its block with its left
+//      neighbour's (same key, different block -> the key is marked "several blocks").  No walk, no divergence: a wave
+//      handles 64 holders whatever the sizes of their keys (a thread per key walked ~25 steps for the longest of its
+//      wave's 64 keys and ~3 for the average one);
+//   D  KEY-parallel: a key whose holders share one block — nearly all after the source reordering — is one record: block
+//      of its first holder, the mask as it stands.  Keys in several blocks: up to FK_SMALL holders in their thread's
+//      registers, above that a whole wave walks the key block by block as k_key_groups does.
+// A key's rank is chunk base + the order in which it is committed; its records take the next places of the chunk's
+// region — one packed LDS atomic hands out both, so record order = rank order.
+struct FkOut {
+    u32* rec_blk;
+    u64* rec_val;
+    u32* nrec;
+    u32* hist;      // chunks x NBT
+    uint4* bigmask;
+    unsigned long long* work;
+};
 // the grouping gave up, the partition overflowed or a bucket was oversize: the host repeats the build, and the kernels
 // queued behind the grouping must not walk tables nobody wrote (known before they start: one decision per launch)
 __device__ inline bool fk_abandoned(const u64* __restrict__ scal) {
     return ((u32)scal[9] | (u32)scal[PC_OVF] | reinterpret_cast<const u32*>(scal + 9)[1]) != 0;
 }
-struct FkOut {
-    u32* rec_blk;
-    u64* rec_val;
-    u32* nrec;
-    u32* hist;      // chunks x mb, or nullptr
-    u32 mb;
-    uint4* bigmask;
-    unsigned long long* work;
-};
-template <class V>
+// (timing build, make fktime: thread 0 of every workgroup adds the shader-clock time of every stage to fk_time[stage])
+#ifdef KSP_FKTIME
+__device__ unsigned long long fk_time[16];
+#define FK_T(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); atomicAdd(&fk_time[k], now_ - t_last_); t_last_ = now_; } } while (0)
+#else
+#define FK_T(k) do { } while (0)
+#endif
+constexpr u32 FK_SMALL = 8;     // holders of a several-block key its thread takes in registers
+constexpr u32 FK_KEYB = 1024;   // keys whose masks are in LDS at a time (a batch with more takes another round)
+constexpr u32 FK_BE = 8192;     // kept holders of a batch of consecutive buckets (staged in LDS together)
+constexpr u32 FK_BK = 4096;     // ... and its kept keys
+constexpr u32 FK_MAXBQ = 4;     // buckets of a batch at most (their loads are unrolled)
+constexpr u32 FK_GBMAX = 32;    // buckets per chunk at most (LDS table of their totals)
+template <class V, u32 NBT>
 __global__ __launch_bounds__(FK_THREADS) void k_fkeys(const V* __restrict__ tags, const u32* __restrict__ kst, const BucketBounds bb,
                                                       const u64* __restrict__ bsum, const u64* __restrict__ bbase, const u32 nbuckets,
-                                                      const u32 gb, const u32* __restrict__ newidx, const u32 nb, const FkOut out,
-                                                      const u32 coop, const u64* __restrict__ scal) {
-    constexpr u32 NT = FK_THREADS, EPT = FK_CAP / NT;
-    __shared__ u32 s_idx[FK_CAP + 4];
-    __shared__ u32 s_kst[FK_KEYS + 2];
-    __shared__ u32 s_big[FK_KEYS / (KG_COOP / 2) + 8], s_nbig;
+                                                      const u32 gb, const u32* __restrict__ newidx, const u32 n_sources, const u32 nb,
+                                                      const FkOut out, const u64* __restrict__ scal) {
+    constexpr u32 NT = FK_THREADS, NWV = NT / 64, HW = FK_BE / 32;
+    typedef typename std::conditional<(NBT * TB <= 65536u && sizeof(V) <= 2), unsigned short, u32>::type IT;   // a tag, then a new source index
+    __shared__ IT s_idx[FK_BE + 4];                 // the batch's holders: tags first, then (in place) new source indices
+    __shared__ unsigned short s_kst[FK_BK + 2];     // first place of every key of the batch, + sentinel
+    __shared__ u32 s_head[HW + 1], s_hpre[HW + 1];
+    __shared__ u32 s_mask[FK_KEYB * 4];
+    __shared__ u32 s_multi[FK_KEYB / 32];
+    __shared__ unsigned short s_big[FK_KEYB];
+    __shared__ u32 s_nbig;
     __shared__ unsigned long long s_cur;                    // records committed so far | keys committed so far << 32
-    __shared__ u32 s_hist[FK_NB_MAX];
-    __shared__ unsigned long long s_work[FK_NB_MAX + 1];
+    __shared__ u32 s_hist[NBT];
+    __shared__ unsigned long long s_work[NBT + 1];
+    __shared__ u32 s_bkept[FK_GBMAX], s_bkeys[FK_GBMAX];
+    static_assert(sizeof(V) <= sizeof(IT), "a tag fits the staging word");
     if (fk_abandoned(scal)) return;
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 bk0 = blockIdx.x * gb, bk1 = min(nbuckets, bk0 + gb);
     const u64 base = bbase[bk0];
     const u32 rbase = (u32)base, kbase = (u32)(base >> 32);
-    const bool do_work = out.work != nullptr;
     if (tid == 0) { s_cur = 0; s_nbig = 0; }
-    if (out.hist) for (u32 i = tid; i < out.mb; i += NT) s_hist[i] = 0;
-    if (do_work) for (u32 i = tid; i <= nb; i += NT) s_work[i] = 0;
+    if (tid < bk1 - bk0) {
+        const u64 t = bsum[bk0 + tid];
+        s_bkept[tid] = min((u32)t, FK_CAP);
+        s_bkeys[tid] = min((u32)(t >> 32), FK_KEYS);
+    }
+    for (u32 i = tid; i < NBT; i += NT) s_hist[i] = 0;
+    for (u32 i = tid; i <= nb; i += NT) s_work[i] = 0;
+    for (u32 i = tid; i <= HW; i += NT) s_head[i] = 0;
     unsigned long long holders = 0;
-    // this bucket's holders as new source indices (registers), the next bucket's while this one is walked
-    u32 kept = 0, nkeys = 0, b0 = 0;
-    u32 pidx[EPT];
-    auto fetch = [&](const u32 b, u32& kept_o, u32& nkeys_o, u32& b0_o) {
-        kept_o = nkeys_o = b0_o = 0;
-        if (b < bk1) {
-            const u64 s = bsum[b];
-            kept_o = min((u32)s, FK_CAP); nkeys_o = min((u32)(s >> 32), FK_KEYS); b0_o = bb.first(b);
-        }
-#pragma unroll
-        for (u32 j = 0; j < EPT; ++j) {
-            const u32 i = tid + j * NT;
-            pidx[j] = i < kept_o ? newidx[src_of_tag(tag_of(tags[b0_o + i]))] : 0u;
-        }
-    };
-    fetch(bk0, kept, nkeys, b0);
-    // one group of a key: block `cur`, members lo | hi -> posting word (a mask of its own for more than INLINE_MAX members)
+    // posting word of one group (block `cur`, members lo | hi); a mask of its own for more than INLINE_MAX members
     auto posting = [&](const u32 fa, const u32 cur, const unsigned long long lo, const unsigned long long hi, u32& bigs, const bool store) -> u32 {
         const u32 cnt = __popcll(lo) + __popcll(hi);
         u32 inf;
@@ -256,162 +304,267 @@ __global__ __launch_bounds__(FK_THREADS) void k_fkeys(const V* __restrict__ tags
                 inf |= id << (7 * j);
             }
         } else {
-            // a group with a mask takes at least INLINE_MAX + 1 of the key's entries: the masks of the key that starts at
-            // entry fa have the places fa / 5, fa / 5 + 1, ... to themselves
+            // a group with a mask takes at least INLINE_MAX + 1 of the key's entries: the masks of the key whose entries begin
+            // at kept entry fa have the places fa / 5, fa / 5 + 1, ... to themselves
             const u32 slot = fa / (INLINE_MAX + 1) + bigs;
             if (store) out.bigmask[slot] = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32));
             inf = BIG | slot;
             ++bigs;
         }
         if (store) {
-            if (out.hist) atomicAdd(&s_hist[cur & (out.mb - 1)], 1u);
-            if (do_work) {
-                holders += cnt;
-                if (cnt > 1) atomicAdd(&s_work[cur], (unsigned long long)cnt * (cnt - 1) / 2);
-            }
+            atomicAdd(&s_hist[cur & (NBT - 1)], 1u);
+            holders += cnt;
+            if (cnt > 1) atomicAdd(&s_work[cur], (unsigned long long)cnt * (cnt - 1) / 2);
         }
         return inf;
     };
-    for (u32 b = bk0; b < bk1; ++b) {
-        __syncthreads();   // (the previous bucket's staging is no longer read; first round: the tables are zeroed)
-#pragma unroll
-        for (u32 j = 0; j < EPT; ++j) {
-            const u32 i = tid + j * NT;
-            if (i < kept) s_idx[i] = pidx[j];
+    __syncthreads();
+#ifdef KSP_FKTIME
+    unsigned long long t_last_ = clock64();
+#endif
+    u32 eseen = 0;   // kept entries of this chunk's buckets before the batch
+    for (u32 bq0 = bk0; bq0 < bk1;) {
+        // the batch: up to FK_MAXBQ consecutive buckets while their holders and keys fit the staging (one bucket always does)
+        u32 bq1 = bq0, ne = 0, nk = 0;
+        while (bq1 < bk1 && bq1 - bq0 < FK_MAXBQ && (bq1 == bq0 || (ne + s_bkept[bq1 - bk0] <= FK_BE && nk + s_bkeys[bq1 - bk0] <= FK_BK))) {
+            ne += s_bkept[bq1 - bk0];
+            nk += s_bkeys[bq1 - bk0];
+            ++bq1;
         }
-        const u32 kb0 = fk_kst_first(b0, b);
-        for (u32 r = tid; r <= nkeys; r += NT) s_kst[r] = kst[kb0 + r] - b0;
-        const u32 c_kept = kept, c_keys = nkeys, c_b0 = b0;
-        (void)c_kept;
-        fetch(b + 1, kept, nkeys, b0);   // (loads in flight during the walk)
-        __syncthreads();
-        for (u32 r = tid; r < c_keys; r += NT) {
-            const u32 f0 = s_kst[r], c = s_kst[r + 1] - f0;
-            if (c > coop) { s_big[atomicAdd(&s_nbig, 1u)] = r; continue; }   // many holders: a whole wave walks this key (below)
-            // first walk: the block of the first holder (for most keys the only block), and how many other blocks there are
-            const u32 bfirst = s_idx[f0] / TB;
-            unsigned long long lo = 0, hi = 0;
-            u32 others = 0, nxt = ~0u;
-            for (u32 i = 0; i < c; i += 4) {
-                u32 t4[4];
+        // ---- A: tags and key starts of every bucket of the batch to LDS.  Straight-line code, every load unconditional at a
+        // clamped (always valid) address: ALL loads of a thread are in flight together — one memory round trip per batch, then
+        // one more (L2: the table is small) for the new source indices.  (Loads inside branches or loops were waited for one
+        // by one: s_waitcnt vmcnt(0) behind each, 24 round trips per batch, 40 % of the kernel.)
+        {
+            constexpr u32 EPB = FK_CAP / NT, KPB = (FK_KEYS + 1 + NT - 1) / NT;
+            const u32 nbq = bq1 - bq0;
+            V tg[FK_MAXBQ][EPB];
+            u32 ks[FK_MAXBQ][KPB], ni[FK_MAXBQ][EPB];
+            u32 kp[FK_MAXBQ], kk[FK_MAXBQ], fb[FK_MAXBQ];
 #pragma unroll
-                for (u32 q = 0; q < 4; ++q) t4[q] = s_idx[f0 + i + q];   // (the staging area has 4 words of slack)
-#pragma unroll
-                for (u32 q = 0; q < 4; ++q) {
-                    if (i + q >= c) break;
-                    const u32 t = t4[q], bq = t / TB;
-                    if (bq == bfirst) {
-                        const u32 l = t % TB;
-                        if (l < 64) lo |= 1ull << l; else hi |= 1ull << (l - 64);
-                    } else { ++others; if (bq < nxt) nxt = bq; }
-                }
+            for (u32 q = 0; q < FK_MAXBQ; ++q) {
+                const u32 bq = bq0 + (q < nbq ? q : 0u);
+                kp[q] = q < nbq ? s_bkept[bq - bk0] : 0u;
+                kk[q] = q < nbq ? s_bkeys[bq - bk0] : 0u;
+                fb[q] = bb.first(bq);
             }
-            // groups of this key: 1 + distinct other blocks (counted by walking them, ascending: rare)
-            u32 groups = 1;
-            if (others) {
-                u32 cur = nxt;
-                while (cur != ~0u) {
-                    ++groups;
-                    u32 n2 = ~0u;
-                    for (u32 i = 0; i < c; ++i) {
-                        const u32 bq = s_idx[f0 + i] / TB;
-                        if (bq > cur && bq != bfirst && bq < n2) n2 = bq;
+#pragma unroll
+            for (u32 q = 0; q < FK_MAXBQ; ++q) {
+                const u32 kb = fk_kst_first(fb[q], bq0 + (q < nbq ? q : 0u));
+#pragma unroll
+                for (u32 j = 0; j < EPB; ++j) tg[q][j] = tags[fb[q] + min(tid + j * NT, max(kp[q], 1u) - 1u)];
+#pragma unroll
+                for (u32 j = 0; j < KPB; ++j) ks[q][j] = kst[kb + min(tid + j * NT, kk[q])];   // (kk + 1 words: the last is the sentinel)
+            }
+#pragma unroll
+            for (u32 q = 0; q < FK_MAXBQ; ++q)
+#pragma unroll
+                for (u32 j = 0; j < EPB; ++j) ni[q][j] = newidx[min(src_of_tag(tag_of(tg[q][j])), n_sources - 1u)];   // (clamped: an unused place holds anything)
+            u32 eo = 0, ko = 0;
+#pragma unroll
+            for (u32 q = 0; q < FK_MAXBQ; ++q) {
+#pragma unroll
+                for (u32 j = 0; j < KPB; ++j) {
+                    const u32 r = tid + j * NT;
+                    if (r < kk[q]) {
+                        const u32 off = eo + (ks[q][j] - fb[q]);
+                        s_kst[ko + r] = (unsigned short)off;
+                        atomicOr(&s_head[off >> 5], 1u << (off & 31));
                     }
-                    cur = n2;
+                }
+#pragma unroll
+                for (u32 j = 0; j < EPB; ++j) {
+                    const u32 i = tid + j * NT;
+                    if (i < kp[q]) s_idx[eo + i] = (IT)ni[q][j];
+                }
+                eo += kp[q];
+                ko += kk[q];
+            }
+            if (tid == 0) s_kst[nk] = (unsigned short)ne;
+        }
+        __syncthreads();
+        FK_T(2);
+        // ---- B: heads in front of every word of the bitmap (256 words: four per lane of one wave)
+        if (wv == 0) {
+            static_assert(HW == 256, "four bitmap words per lane");
+            u32 c[4], t = 0;
+#pragma unroll
+            for (u32 q = 0; q < 4; ++q) { c[q] = (u32)__popc(s_head[4 * lane + q]); t += c[q]; }
+            u32 inc = t;
+            for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+            u32 run = inc - t;
+#pragma unroll
+            for (u32 q = 0; q < 4; ++q) { s_hpre[4 * lane + q] = run; run += c[q]; }
+        }
+        const u32 ebatch = rbase + eseen;   // kept-entry number of the batch's first holder
+        FK_T(3);
+        for (u32 kb = 0; kb < max(nk, 1u); kb += FK_KEYB) {   // (one round for nearly every batch)
+            const u32 kn = min(FK_KEYB, nk - kb);
+            if (kb) __syncthreads();   // (the previous round's masks have been read)
+            for (u32 i = tid; i < kn * 4; i += NT) s_mask[i] = 0;
+            for (u32 i = tid; i < (kn + 31) / 32; i += NT) s_multi[i] = 0;
+            __syncthreads();
+            FK_T(4);
+            // ---- C: every holder ORs its bit into its key's mask; a holder in another block than its left neighbour marks the key
+            for (u32 i0 = tid; i0 < ne; i0 += 4 * NT) {   // (four holders per pass: their LDS reads are independent)
+                u32 w[4], hp[4], t[4], tl[4];
+#pragma unroll
+                for (u32 u = 0; u < 4; ++u) {
+                    const u32 i = i0 + u * NT, ic = min(i, ne - 1);
+                    w[u] = s_head[ic >> 5]; hp[u] = s_hpre[ic >> 5]; t[u] = s_idx[ic]; tl[u] = ic ? (u32)s_idx[ic - 1] : 0u;
+                }
+#pragma unroll
+                for (u32 u = 0; u < 4; ++u) {
+                    const u32 i = i0 + u * NT;
+                    if (i >= ne) break;
+                    const u32 k = hp[u] + (u32)__popc(w[u] & (0xFFFFFFFFu >> (31 - (i & 31)))) - 1 - kb;   // (heads at or below place i) - 1
+                    if (k < kn) {
+                        if (!((w[u] >> (i & 31)) & 1u) && tl[u] / TB != t[u] / TB) atomicOr(&s_multi[k >> 5], 1u << (k & 31));
+                        atomicOr(&s_mask[k * 4 + ((t[u] % TB) >> 5)], 1u << (t[u] & 31));
+                    }
                 }
             }
-            const unsigned long long old = atomicAdd(&s_cur, (unsigned long long)groups | (1ull << 32));
-            const u32 pos = rbase + (u32)old, rank = kbase + (u32)(old >> 32);
-            const u32 fa = c_b0 + f0;
-            u32 bigs = 0;
-            out.rec_blk[pos] = bfirst;
-            out.rec_val[pos] = ((u64)rank << 32) | posting(fa, bfirst, lo, hi, bigs, true);
-            if (others) {
-                u32 cur = nxt, g = 1;
-                while (cur != ~0u) {
-                    u32 n2 = ~0u;
-                    lo = hi = 0;
-                    for (u32 i = 0; i < c; ++i) {
-                        const u32 t = s_idx[f0 + i], bq = t / TB;
-                        if (bq == cur) {
-                            const u32 l = t % TB;
+            __syncthreads();
+            FK_T(5);
+            // ---- D: a key per thread
+            for (u32 k0 = 0; k0 < kn; k0 += NT) {   // (uniform trip count: the waves reserve together)
+                const u32 kk = k0 + tid;
+                const bool have = kk < kn;
+                const u32 r = kb + kk;
+                const u32 f0 = have ? s_kst[r] : 0u, c = have ? s_kst[r + 1] - f0 : 0u;
+                const u32 fa = ebatch + f0;
+                const bool multi = have && ((s_multi[kk >> 5] >> (kk & 31)) & 1u);
+                // keys with all holders in one block — one record each: the wave reserves their places and ranks with ONE atomic
+                const bool single = have && !multi;
+                const unsigned long long sm = __ballot(single);
+                unsigned long long old = 0;
+                if (sm) {
+                    const u32 ns = (u32)__popcll(sm);
+                    if (lane == (u32)__ffsll((long long)sm) - 1) old = atomicAdd(&s_cur, (unsigned long long)ns | ((unsigned long long)ns << 32));
+                    old = __shfl(old, __ffsll((long long)sm) - 1);
+                }
+                if (single) {
+                    const u32 mine = (u32)__popcll(sm & ((1ull << lane) - 1ull));
+                    const u32 bfirst = (u32)s_idx[f0] / TB;
+                    const unsigned long long lo = (unsigned long long)s_mask[kk * 4] | ((unsigned long long)s_mask[kk * 4 + 1] << 32);
+                    const unsigned long long hi = (unsigned long long)s_mask[kk * 4 + 2] | ((unsigned long long)s_mask[kk * 4 + 3] << 32);
+                    const u32 pos = rbase + (u32)old + mine, rank = kbase + (u32)(old >> 32) + mine;
+                    u32 bigs = 0;
+                    out.rec_blk[pos] = bfirst;
+                    out.rec_val[pos] = ((u64)rank << 32) | posting(fa, bfirst, lo, hi, bigs, true);
+                }
+                if (!multi) continue;
+                if (c > FK_SMALL) { s_big[atomicAdd(&s_nbig, 1u)] = (unsigned short)r; continue; }   // several blocks, more than a handful of holders: a whole wave (below)
+                // several blocks, a handful of holders (the common case of unrelated sources): all of them in registers, one
+                // record per distinct block, in order of first appearance
+                u32 t[FK_SMALL];
+#pragma unroll
+                for (u32 q = 0; q < FK_SMALL; ++q) t[q] = q < c ? (u32)s_idx[f0 + q] : ~0u;
+                u32 groups = 0;
+#pragma unroll
+                for (u32 q = 0; q < FK_SMALL; ++q) {
+                    bool fresh = q < c;
+#pragma unroll
+                    for (u32 p2 = 0; p2 < q; ++p2) fresh = fresh && (t[p2] / TB != t[q] / TB);
+                    groups += fresh ? 1u : 0u;
+                }
+                const unsigned long long o2 = atomicAdd(&s_cur, (unsigned long long)groups | (1ull << 32));
+                const u32 pos = rbase + (u32)o2, rank = kbase + (u32)(o2 >> 32);
+                u32 g = 0, bigs = 0;
+#pragma unroll
+                for (u32 q = 0; q < FK_SMALL; ++q) {
+                    bool fresh = q < c;
+#pragma unroll
+                    for (u32 p2 = 0; p2 < q; ++p2) fresh = fresh && (t[p2] / TB != t[q] / TB);
+                    if (!fresh) continue;
+                    const u32 cur = t[q] / TB;
+                    unsigned long long lo = 0, hi = 0;
+#pragma unroll
+                    for (u32 p2 = q; p2 < FK_SMALL; ++p2) {
+                        if (p2 < c && t[p2] / TB == cur) {
+                            const u32 l = t[p2] % TB;
                             if (l < 64) lo |= 1ull << l; else hi |= 1ull << (l - 64);
-                        } else if (bq > cur && bq != bfirst && bq < n2) n2 = bq;
+                        }
                     }
                     out.rec_blk[pos + g] = cur;
                     out.rec_val[pos + g] = ((u64)rank << 32) | posting(fa, cur, lo, hi, bigs, true);
                     ++g;
-                    cur = n2;
                 }
             }
-        }
-        __syncthreads();
-        // keys with many holders, one wave each: the lanes share the walk, the masks and the next block are reduced
-        const u32 nbig = s_nbig;
-        for (u32 q = wv; q < nbig; q += NT / 64) {
-            const u32 r = s_big[q];
-            const u32 f0 = s_kst[r], c = s_kst[r + 1] - f0;
-            const u32 bfirst = s_idx[f0] / TB;
-            // count the groups: distinct blocks among the holders (first block first, then ascending)
-            u32 groups = 0;
-            {
-                u32 cur = bfirst;
-                while (cur != ~0u) {
-                    ++groups;
-                    u32 n2 = ~0u;
-                    const u32 floor_b = groups == 1 ? 0u : cur + 1;
-                    for (u32 i = lane; i < c; i += 64) {
-                        const u32 bq = s_idx[f0 + i] / TB;
-                        if (bq != cur && bq >= floor_b && bq != bfirst && bq < n2) n2 = bq;
+            // keys in several blocks with more holders, one wave each: the lanes share the walk (the first holder's block first,
+            // then the others ascending, as k_key_groups), masks and next block are reduced
+            __syncthreads();
+            FK_T(6);
+            const u32 nbig = s_nbig;
+            for (u32 q = wv; q < nbig; q += NWV) {
+                const u32 r = s_big[q];
+                const u32 f0 = s_kst[r], c = s_kst[r + 1] - f0;
+                const u32 bfirst = (u32)s_idx[f0] / TB;
+                u32 groups = 0;
+                {
+                    u32 cur = bfirst;
+                    while (cur != ~0u) {
+                        ++groups;
+                        u32 n2 = ~0u;
+                        const u32 floor_b = groups == 1 ? 0u : cur + 1;
+                        for (u32 i = lane; i < c; i += 64) {
+                            const u32 bq = (u32)s_idx[f0 + i] / TB;
+                            if (bq != cur && bq >= floor_b && bq != bfirst && bq < n2) n2 = bq;
+                        }
+                        for (int o = 32; o; o >>= 1) n2 = min(n2, (u32)__shfl_xor(n2, o));
+                        cur = n2;
                     }
-                    for (int o = 32; o; o >>= 1) n2 = min(n2, (u32)__shfl_xor(n2, o));
+                }
+                unsigned long long old = 0;
+                if (lane == 0) old = atomicAdd(&s_cur, (unsigned long long)groups | (1ull << 32));
+                old = __shfl(old, 0);
+                const u32 pos = rbase + (u32)old, rank = kbase + (u32)(old >> 32);
+                const u32 fa = ebatch + f0;
+                u32 cur = bfirst, g = 0, bigs = 0;
+                while (cur != ~0u) {
+                    u32 n2 = ~0u;
+                    unsigned long long lo = 0, hi = 0;
+                    const u32 floor_b = g == 0 ? 0u : cur + 1;
+                    for (u32 i = lane; i < c; i += 64) {
+                        const u32 t = s_idx[f0 + i], bq = t / TB;
+                        if (bq == cur) {
+                            const u32 l = t % TB;
+                            if (l < 64) lo |= 1ull << l; else hi |= 1ull << (l - 64);
+                        } else if (bq >= floor_b && bq != bfirst && bq < n2) n2 = bq;
+                    }
+                    for (int o = 32; o; o >>= 1) {
+                        lo |= __shfl_xor(lo, o);
+                        hi |= __shfl_xor(hi, o);
+                        n2 = min(n2, (u32)__shfl_xor(n2, o));
+                    }
+                    const u32 inf = posting(fa, cur, lo, hi, bigs, lane == 0);
+                    if (lane == 0) {
+                        out.rec_blk[pos + g] = cur;
+                        out.rec_val[pos + g] = ((u64)rank << 32) | inf;
+                    }
+                    ++g;
                     cur = n2;
                 }
             }
-            unsigned long long old = 0;
-            if (lane == 0) old = atomicAdd(&s_cur, (unsigned long long)groups | (1ull << 32));
-            old = __shfl(old, 0);
-            const u32 pos = rbase + (u32)old, rank = kbase + (u32)(old >> 32);
-            const u32 fa = c_b0 + f0;
-            u32 cur = bfirst, g = 0, bigs = 0;
-            while (cur != ~0u) {
-                u32 n2 = ~0u;
-                unsigned long long lo = 0, hi = 0;
-                const u32 floor_b = g == 0 ? 0u : cur + 1;
-                for (u32 i = lane; i < c; i += 64) {
-                    const u32 t = s_idx[f0 + i], bq = t / TB;
-                    if (bq == cur) {
-                        const u32 l = t % TB;
-                        if (l < 64) lo |= 1ull << l; else hi |= 1ull << (l - 64);
-                    } else if (bq >= floor_b && bq != bfirst && bq < n2) n2 = bq;
-                }
-                for (int o = 32; o; o >>= 1) {
-                    lo |= __shfl_xor(lo, o);
-                    hi |= __shfl_xor(hi, o);
-                    n2 = min(n2, (u32)__shfl_xor(n2, o));
-                }
-                const u32 inf = posting(fa, cur, lo, hi, bigs, lane == 0);
-                if (lane == 0) {
-                    out.rec_blk[pos + g] = cur;
-                    out.rec_val[pos + g] = ((u64)rank << 32) | inf;
-                }
-                ++g;
-                cur = n2;
+            if (nbig) {
+                __syncthreads();
+                if (tid == 0) s_nbig = 0;
             }
         }
-        __syncthreads();
-        if (tid == 0) s_nbig = 0;
+        for (u32 i = tid; i <= HW; i += NT) s_head[i] = 0;   // (the next batch's bitmap: last read in C)
+        __syncthreads();   // (the batch's tables are rebuilt from here on)
+        FK_T(7);
+        eseen += ne;
+        bq0 = bq1;
     }
-    __syncthreads();
     if (tid == 0) out.nrec[blockIdx.x] = (u32)s_cur;
-    if (out.hist) for (u32 i = tid; i < out.mb; i += NT) out.hist[(size_t)blockIdx.x * out.mb + i] = s_hist[i];
-    if (do_work) {
-        for (int o = 32; o > 0; o >>= 1) holders += __shfl_down(holders, o);
-        if (lane == 0 && holders) atomicAdd(&s_work[nb], holders);
-        __syncthreads();
-        for (u32 i = tid; i <= nb; i += NT)
-            if (s_work[i]) atomicAdd(&out.work[i], s_work[i]);
-    }
+    for (u32 i = tid; i < NBT; i += NT) out.hist[(size_t)blockIdx.x * NBT + i] = s_hist[i];
+    for (int o = 32; o > 0; o >>= 1) holders += __shfl_down(holders, o);
+    if (lane == 0 && holders) atomicAdd(&s_work[nb], holders);
+    __syncthreads();
+    for (u32 i = tid; i <= nb; i += NT)
+        if (s_work[i]) atomicAdd(&out.work[i], s_work[i]);
+    FK_T(8);
 }
 
 // ---- the chunk regions to the padded block lists -------------------------------------------------------------------

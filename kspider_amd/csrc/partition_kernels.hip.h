@@ -548,7 +548,6 @@ __global__ __launch_bounds__(64 * SEG_BW) void k_seg_bounds(const u64* __restric
                                                             const u64* __restrict__ scal, const u64* __restrict__ kmin, const int pb2,
                                                             const u32 nbm1, const u32 nb1, u32* __restrict__ bnd) {
     __shared__ u32 s_rl[SEG_BW * SEG_BWIN + 1];   // [1 + w]: range of the last key of window w; [0]: of the entry in front of the chunk
-    __shared__ u64 s_kmin[260];                   // the boundary keys (read with a uniform address: one broadcast each)
     __shared__ u32 s_bnd[260];                    // the boundaries this chunk crosses: they leave in one piece (single words per
                                                   // boundary were 2 M partial-line writes per build)
     const u32 lane = threadIdx.x & 63;
@@ -564,7 +563,7 @@ __global__ __launch_bounds__(64 * SEG_BW) void k_seg_bounds(const u64* __restric
     const u32 ident = reinterpret_cast<const u32*>(scal + PC_MODE)[0];
     u32* const row = bnd + (size_t)s * (nb1 + 1);
     if (a0 == 0 && threadIdx.x == 0) row[0] = 0;
-    for (u32 j = threadIdx.x; j <= nb1; j += 64 * SEG_BW) s_kmin[j] = kmin[j];
+    (void)kmin;   // (the boundary keys of round 2's scalar formulation; k_seg_scatter does not need them either)
     u64 k[SEG_BWIN];
 #pragma unroll
     for (u32 q = 0; q < SEG_BWIN; ++q) {
@@ -580,33 +579,33 @@ __global__ __launch_bounds__(64 * SEG_BW) void k_seg_bounds(const u64* __restric
         }
         if (lane == 0) s_rl[0] = c0;
     }
-    u32 rl[SEG_BWIN];
+    // Every lane works out the range of its own keys on the VECTOR unit (a 64 x 64 -> high 64 multiply each).  Round 2 did
+    // this once per window on the scalar unit (the keys of a window ascend: only its last key matters) and then looped over
+    // the boundaries with compare + ballot + popcount — ~70 scalar instructions per window, and a compute unit issues ONE
+    // scalar instruction per cycle for all its 32 waves: the counters showed 6.5e7 scalar against 2.2e7 vector instructions
+    // per launch, 554 per wave x 32 resident waves = the waves' whole lifetime.  The scalar unit was the kernel's limit.
+    u32 r[SEG_BWIN];
 #pragma unroll
     for (u32 q = 0; q < SEG_BWIN; ++q) {
         const u32 w = q * SEG_BW + wv, w0 = a0 + w * 64;
-        rl[q] = 0;
-        if (w0 < a1) {   // (uniform)
-            const u32 nv = min(64u, a1 - w0);
-            const u64 klast = (u64)(u32)__builtin_amdgcn_readlane((u32)k[q], nv - 1) | ((u64)(u32)__builtin_amdgcn_readlane((u32)(k[q] >> 32), nv - 1) << 32);
-            rl[q] = seg_range_of(klast, mult, ident, nbm1, pb2);
-            if (lane == 0) s_rl[1 + w] = rl[q];
-        }
+        r[q] = seg_range_of(k[q], mult, ident, nbm1, pb2);
+        if (w0 < a1 && lane == min(64u, a1 - w0) - 1) s_rl[1 + w] = r[q];   // the window's last key
     }
     __syncthreads();
 #pragma unroll
     for (u32 q = 0; q < SEG_BWIN; ++q) {
         const u32 w = q * SEG_BW + wv, w0 = a0 + w * 64;
         if (w0 >= a1) break;   // (uniform)
-        const u32 nv = min(64u, a1 - w0);
-        const unsigned long long vm = nv >= 64 ? ~0ull : (1ull << nv) - 1ull;   // valid lanes of this window
-        const u64 kl = k[q];
-        const u32 carry = __builtin_amdgcn_readfirstlane(s_rl[w]);   // range of the entry in front of this window
-        for (u32 j = carry + 1; j <= rl[q]; ++j) {   // (uniform; ranges ascend with the keys)
-            const u32 below = (u32)__popcll(__ballot(kl < s_kmin[j]) & vm);
-            if (lane == 0) s_bnd[j] = w0 + below;
+        const u32 i = w0 + lane;
+        // the range of the entry in front of mine: my left neighbour's, or (lane 0) the last key of the window before
+        const u32 up = __shfl_up(r[q], 1);
+        const u32 prev = lane ? up : s_rl[w];
+        if (i < a1)
+            for (u32 j = prev + 1; j <= r[q]; ++j) s_bnd[j] = i;   // I am the first entry of range j or a later one (ranges ascend with the keys)
+        if (w0 + 64 >= a1 && last_chunk) {   // the run's last window: the ranges behind its last key are empty, they begin at the end
+            const u32 rlast = __shfl(r[q], min(64u, a1 - w0) - 1);
+            for (u32 j = rlast + 1 + lane; j <= nb1; j += 64) row[j] = len;
         }
-        if (w0 + 64 >= a1 && last_chunk)   // the run's last window: the ranges behind its last key are empty, they begin at the end
-            for (u32 j = rl[q] + 1 + lane; j <= nb1; j += 64) row[j] = len;
     }
     __syncthreads();
     {   // boundaries (range in front of the chunk, range of its last key]: written by exactly one window each

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["default", "no_reorder", "dense_walk", "collect", "lds_counters", "sort_grouping", "sort_lists",
-                                      "rocprim_partition", "match_join", "plain_cuts", "library_split", "pass_by_pass"])
+                                      "rocprim_partition", "match_join", "plain_cuts", "library_split", "bucket_resident"])
 def mode(request, monkeypatch):
     """Every case runs seven ways (the last two: keys grouped by the full sort instead of the hash buckets,
     KSP_HASH_GROUP=0; block lists by sorting the entries by block instead of key by key, KSP_KEY_GROUPS=0): as shipped (sources reordered by shared-key label, join over the
@@ -22,8 +22,8 @@ def mode(request, monkeypatch):
     the off-diagonal accumulation forced to the bit-sliced collect path / to the LDS counters."""
     for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_HASH_GROUP", "KSP_KEY_GROUPS", "KSP_PARTITION", "KSP_JOIN", "KSP_ALIGN", "KSP_MS", "KSP_FUSED"):
         monkeypatch.delenv(k, raising=False)
-    if request.param == "pass_by_pass":   # the middle of stage 1 pass by pass (k_bucket_group ... k_move_groups) instead of bucket-resident
-        monkeypatch.setenv("KSP_FUSED", "0")
+    if request.param == "bucket_resident":   # the middle of stage 1 bucket-resident (k_fgroup / k_fkeys / k_fms_place) instead of pass by pass
+        monkeypatch.setenv("KSP_FUSED", "1")
     if request.param == "library_split":   # the group records sorted by block with the library's radix sort instead of k_ms_*
         monkeypatch.setenv("KSP_MS", "0")
     if request.param == "plain_cuts":   # blocks cut every 128 sources of the label order (no spare blocks, no holes)
