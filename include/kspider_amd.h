@@ -118,6 +118,19 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
  * device does not idle while the host collects the count and hands the edges on (bench.py does exactly that). */
 int ksp_engine_join_launch(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_edge* d_edges, uint64_t capacity, void* stream);
 int ksp_engine_join_wait(ksp_engine* e, uint64_t* h_count);
+/* A pipelined caller cannot retry an overflowed join: KSP_E_OVERFLOW is only reported by _wait, and by then the next
+ * build has replaced the lists (and the tile numbering) the join ran on.  Size the buffer from ksp_engine_edge_bound
+ * before _launch — the bound is exact enough to allocate by — and treat KSP_E_OVERFLOW from _wait as "this step's
+ * result is incomplete, run the step again".                                                                     */
+
+/* Join tiles [tile_begin, tile_end) and deliver the edges in HOST memory (h_edges: `capacity` edges, pinned memory
+ * for full PCIe rate): the range is cut into pieces by the edge bound, piece k + 1 is joined while piece k is copied
+ * on a stream of the engine's own.  For results of hundreds of MB (100k genomes: 45 M pairs), whose copy would
+ * otherwise follow the join.  *h_count = pairs found; KSP_E_OVERFLOW if that exceeds capacity (*h_count is still the
+ * full count: allocate and call again).  Returns when everything has arrived.  The pair map of the reference lives
+ * in host memory throughout (src/pairwise.cpp:191); this is the step that gets the device's result there.          */
+int ksp_engine_join_to_host(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_edge* h_edges, uint64_t capacity,
+                            uint64_t* h_count, void* stream);
 
 int ksp_engine_get_stats(const ksp_engine* e, ksp_stats* out);
 /* Per-phase HIP-event times of stage 1 (the reference's own phase timers, src/pairwise.cpp:131-133,155,181,

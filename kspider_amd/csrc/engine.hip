@@ -197,6 +197,9 @@ struct ksp_engine {
     hipEvent_t ev_join_done = nullptr;   // behind the count copy of the last ksp_engine_join_launch
     hipEvent_t ev_rb = nullptr;          // behind a read-back the host waits for while later kernels are already queued
     double kept_frac = 0.7;              // kept / all entries of the previous build (label sampling before the count is known)
+    ksp::Buf stage[2];                   // ksp_engine_join_to_host: the edges of a piece wait here for their copy
+    hipStream_t copy_stream = nullptr;   // ... which runs on this stream, under the join of the next piece
+    hipEvent_t ev_copy[2] = {nullptr, nullptr};
     bool join_pending = false;           // a launched join whose count has not been collected (ksp_engine_join_wait)
     u64 join_cap = 0;
     ksp_stats jst{};                     // last_* of the launched join
@@ -1351,8 +1354,10 @@ void ksp_engine_destroy(ksp_engine* e) {
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
                         &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
                         &e->d_wg, &e->gp, &e->gm, &e->ms_hist, &e->pmask, &e->crank, &e->PK, &e->PT, &e->PD, &e->parena, &e->PK2, &e->PT2, &e->PD2, &e->seg_tbl, &e->seg_grp, &e->seg_chk, &e->biglist, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
-                        &e->mr0, &e->mr1, &e->mstart};
+                        &e->mr0, &e->mr1, &e->mstart, &e->stage[0], &e->stage[1]};
     for (auto* b : bufs) b->release();
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    for (int i = 0; i < 2; ++i) if (e->ev_copy[i]) (void)hipEventDestroy(e->ev_copy[i]);
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
     if (e->h_sched) (void)hipHostFree(e->h_sched);
@@ -2220,6 +2225,97 @@ int ksp_engine_join(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_e
     int rc = ksp_engine_join_launch(e, tile_begin, tile_end, d_edges, capacity, stream);
     if (rc) return rc;
     return ksp_engine_join_wait(e, h_count);
+}
+
+// The edges of tiles [tile_begin, tile_end) straight into the caller's (pinned) host buffer: the range is cut into
+// pieces by the edge bound, piece k + 1 is joined while piece k travels over PCIe on a stream of its own.  The
+// reference has no such step (its pair map lives in host memory, src/pairwise.cpp:191); here the result of the
+// large configurations is hundreds of MB and its copy was a third to a half of their step when it followed the join.
+int ksp_engine_join_to_host(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end, ksp_edge* h_edges, uint64_t capacity,
+                            uint64_t* h_count, void* stream) {
+    if (!e || !h_count) { set_error("join_to_host: NULL argument"); return KSP_E_ARG; }
+    *h_count = 0;
+    if (!e->built) { set_error("join: build_blocks has not been run"); return KSP_E_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    KSP_HIP(hipSetDevice(e->device));
+    const u64 T = ksp_engine_num_tiles(e);
+    if (tile_end > T) tile_end = T;
+    if (tile_begin >= tile_end) return KSP_OK;
+    if (!e->copy_stream) KSP_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i)
+        if (!e->ev_copy[i]) KSP_HIP(hipEventCreateWithFlags(&e->ev_copy[i], hipEventDisableTiming));
+    // Pieces of whole tiles.  The staging buffers hold `cap` edges; the first piece is cut by the edge BOUND (it cannot
+    // overflow), the later ones by the bound x the densest ratio of found / bound seen so far (+ 50 %): with clustered
+    // sources a few per cent of a tile's pairs share anything (1M read groups: 4.5 %), and pieces cut by the bound alone
+    // were dozens of small launches.  A piece that does overflow its staging buffer is joined again, halved.
+    u64 cap = 1ull << 24;   // 256 MB of edges per staging buffer
+    if (const char* pv = std::getenv("KSP_DEBUG_PIECE")) cap = std::max<u64>((u64)TB * TB, std::strtoull(pv, nullptr, 10));
+    int rc = KSP_OK;
+    for (int i = 0; i < 2; ++i)
+        if ((rc = e->stage[i].ensure((cap + 16) * sizeof(ksp_edge)))) return rc;
+    const std::vector<u32>& P = e->h_blk_src;
+    size_t ai = e->sched_on ? std::lower_bound(e->act_tid.begin(), e->act_tid.end(), tile_begin) - e->act_tid.begin() : 0;
+    const size_t a_end = e->sched_on ? std::lower_bound(e->act_tid.begin(), e->act_tid.end(), tile_end) - e->act_tid.begin() : 0;
+    u64 total = 0;
+    float ms = 0;
+    u64 tiles = 0, act = 0, pairs = 0, bytes = 0;
+    bool overflow = false;
+    double ratio = 0;      // densest found / bound so far (0: nothing joined yet)
+    u64 shrink = 1;        // (a piece that overflowed: the limit divided by this until one fits)
+    u64 t = tile_begin;
+    for (u32 k = 0; t < tile_end;) {
+        u64 limit = ratio > 0 ? (u64)((double)cap / (1.5 * ratio)) : cap;
+        limit = std::max<u64>(limit / shrink, 1);
+        // the piece [t, t_next): whole tiles while their bound fits the limit (one tile at least)
+        u64 t_next = tile_end, bound = 0;
+        size_t aj = ai;
+        if (e->sched_on) {
+            for (; aj < a_end; ++aj) {
+                const u32 I = e->act_rec[4 * aj], J = e->act_rec[4 * aj + 1];
+                const u64 nI = P[I + 1] - P[I], nJ = P[J + 1] - P[J];
+                const u64 b = (I == J) ? nI * (nI ? nI - 1 : 0) / 2 : nI * nJ;
+                if (bound && bound + b > limit) { t_next = e->act_tid[aj]; break; }
+                bound += b;
+            }
+        } else {
+            const u64 per = std::max<u64>(1, limit / ((u64)TB * TB));
+            t_next = std::min(tile_end, t + per);
+            bound = ksp_engine_tile_pairs(e, t, t_next);
+        }
+        Buf& sb = e->stage[k & 1];
+        if (k >= 2) KSP_HIP(hipStreamWaitEvent(st, e->ev_copy[k & 1], 0));   // (the copy that last read this staging buffer)
+        u64 cnt = 0;
+        rc = ksp_engine_join(e, t, t_next, sb.as<ksp_edge>(), cap + 16, &cnt, st);   // (returns when the piece is joined; the piece before is on its way meanwhile)
+        ms += e->st.ms_join;
+        if (rc == KSP_E_OVERFLOW && (t_next > t + 1) && shrink < (1ull << 40)) {   // denser than anything before: the same tiles in smaller pieces
+            if (bound) ratio = std::max(ratio, std::min(1.0, (double)cnt / (double)bound));
+            shrink *= 2;
+            continue;
+        }
+        if (rc) return rc;
+        shrink = 1;
+        if (bound) ratio = std::max(ratio, std::min(1.0, (double)cnt / (double)bound));
+        tiles += e->st.last_tiles; act += e->st.last_active_tiles; pairs += e->st.last_pairs; bytes += e->st.last_stream_bytes;
+        if (total + cnt > capacity) overflow = true;
+        else if (cnt) {
+            if (!h_edges) { set_error("join_to_host: h_edges is NULL"); return KSP_E_ARG; }
+            KSP_HIP(hipMemcpyAsync(h_edges + total, sb.p, cnt * sizeof(ksp_edge), hipMemcpyDeviceToHost, e->copy_stream));
+        }
+        KSP_HIP(hipEventRecord(e->ev_copy[k & 1], e->copy_stream));
+        total += cnt;
+        t = t_next;
+        ai = aj;
+        ++k;
+    }
+    KSP_HIP(hipStreamSynchronize(e->copy_stream));
+    *h_count = total;
+    e->st.ms_join = ms; e->st.last_tiles = tiles; e->st.last_active_tiles = act; e->st.last_pairs = pairs; e->st.last_stream_bytes = bytes;
+    e->st.last_edges = total;
+    if (overflow) {
+        set_error("join_to_host: host buffer too small (" + std::to_string(total) + " > " + std::to_string(capacity) + ")");
+        return KSP_E_OVERFLOW;
+    }
+    return KSP_OK;
 }
 
 int ksp_engine_set_profiling(ksp_engine* e, int on) {

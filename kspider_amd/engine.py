@@ -22,7 +22,7 @@ KSP_OK, KSP_E_ARG, KSP_E_HIP, KSP_E_IO, KSP_E_OVERFLOW, KSP_E_LIMIT = range(6)
 ABI_SYMBOLS = [
     "ksp_last_error", "ksp_device_count", "ksp_engine_create", "ksp_engine_destroy",
     "ksp_engine_build_blocks", "ksp_engine_num_tiles", "ksp_engine_tile_pairs", "ksp_engine_join",
-    "ksp_engine_join_launch", "ksp_engine_join_wait",
+    "ksp_engine_join_launch", "ksp_engine_join_wait", "ksp_engine_join_to_host",
     "ksp_engine_get_stats", "ksp_device_malloc", "ksp_device_free", "ksp_memcpy_h2d", "ksp_memcpy_d2h",
     "ksp_pairwise_host", "ksp_free", "kspider_pairwise", "ksp_index_info", "ksp_format_float",
     "kspider_pairwise_sigs", "kspider_pairwise_bins",
@@ -334,6 +334,20 @@ class Engine:
     def join_wait(self) -> int:
         cnt = ctypes.c_uint64(0)
         _check(lib().ksp_engine_join_wait(self._h, ctypes.byref(cnt)))
+        return int(cnt.value)
+
+    def join_to_host(self, t0: int, t1: int, h_edges_ptr: int, capacity: int, stream: int = 0) -> int:
+        """Join tiles [t0, t1) piece by piece, every piece copied to (pinned) host memory under the join of the next."""
+        cnt = ctypes.c_uint64(0)
+        L = lib()
+        L.ksp_engine_join_to_host.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64,
+                                              ctypes.c_void_p, ctypes.c_void_p]
+        rc = L.ksp_engine_join_to_host(self._h, t0, t1, h_edges_ptr or None, capacity, ctypes.byref(cnt), stream or None)
+        if rc == KSP_E_OVERFLOW:
+            err = KspError(rc, L.ksp_last_error().decode())
+            err.count = int(cnt.value)
+            raise err
+        _check(rc)
         return int(cnt.value)
 
     def join(self, t0: int, t1: int, d_edges_ptr: int, capacity: int, stream: int = 0) -> int:
