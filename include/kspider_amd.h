@@ -239,6 +239,23 @@ int kspider_pairwise_bins(const char* bins_dir, const char* out_prefix, int user
 int kspider_cluster(const char* index_prefix, const char* dist_type, double cutoff);
 int ksp_components(int device, uint32_t n_nodes, const uint32_t* h_a, const uint32_t* h_b, uint64_t n_edges,
                    uint32_t* h_label);
+/* Clustering from HBM — what SURVEY 8f N4 is for: the pairs never leave the device as text.
+ * ksp_components_edges: components straight over the join's edge records.  d_edges: `n_edges` ksp_edge records in
+ *   DEVICE memory (as ksp_engine_join leaves them; node = source index), d_kmer_counts[v] = k-mer count of source v
+ *   (device memory).  An edge counts when its containment column dist_col (3 min, 4 avg, 5 max; single-precision maths
+ *   of src/pairwise.cpp:260-264) passes the reference's test: text of the float with 6 significant digits -> float ->
+ *   x 100 -> not below cutoff x 100 (ks_clustering.py:101-105; a NaN passes).  That test is monotone in the float, so
+ *   the device compares against the one critical float found on the host — the same rows pass, digit for digit.
+ *   h_label[v] = smallest source index of v's component.
+ * kspider_pairwise_and_cluster: `kSpider pairwise` followed by `kSpider cluster` (ks_clustering.py:63-137) in ONE
+ *   device pass: writes PREFIX_kSpider_seqToKmersNo.tsv and PREFIX_kSpider_pairwise.tsv exactly as kspider_pairwise
+ *   and PREFIX_kSpider_clusters_<cutoff*100>%.tsv exactly as kspider_cluster would from that TSV — but the components
+ *   come from the edges while they are in HBM (the TSV is never read back).  dist_type: "min_cont", "avg_cont",
+ *   "max_cont" (NULL / ""); "ani" needs the separate ANI column file and stays with kspider_cluster.  Reads
+ *   PREFIX.namesMap like kspider_cluster.                                                                          */
+int ksp_components_edges(int device, uint32_t n_nodes, const ksp_edge* d_edges, uint64_t n_edges, const uint32_t* d_kmer_counts,
+                         int dist_col, double cutoff, uint32_t* h_label);
+int kspider_pairwise_and_cluster(const char* index_prefix, int user_threads, const char* dist_type, double cutoff);
 
 /* ---- host-only diagnostics (no GPU needed) -------------------------------------------
  * ksp_index_info: parse the three index files and report what the reader detected:

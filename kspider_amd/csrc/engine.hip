@@ -2468,6 +2468,7 @@ struct MultiJob {
     const u64* key_off = nullptr; const u32* sources = nullptr; const u32* key_weights = nullptr;
     u32 n_keys = 0, n_sources = 0;
     bool postings = false;
+    ksp::CcRequest* cc = nullptr;   // also wanted: the components of the result, from the edges while they are on the device
 };
 }  // namespace
 
@@ -2639,6 +2640,17 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
         if (i == 0) {
             ksp_edge* d_all = nd > 1 ? merged.as<ksp_edge>() : D.edges.as<ksp_edge>();
             if (total && (rc = sort_edges_device(d_all, total, N))) { fail(rc); return; }
+            if (job.cc && job.cc->labels) {   // clustering from HBM: the edges never travel to the host and back as text for this
+                job.cc->labels->assign((size_t)N, 0);
+                Buf d_cnt;
+                if (N && ((rc = d_cnt.ensure((size_t)N * 4)) || (rc = ksp_memcpy_h2d(d_cnt.p, job.cc->kmer_counts, (u64)N * 4)) ||
+                          (rc = cc_edges_on_device(N, d_all, total, d_cnt.as<u32>(), job.cc->col, job.cc->cutoff, job.cc->labels->data(), &job.cc->n_kept)))) {
+                    d_cnt.release();
+                    fail(rc);
+                    return;
+                }
+                d_cnt.release();
+            }
             ksp_edge* out = (ksp_edge*)alloc_result(total * sizeof(ksp_edge));
             if (!out) { set_error("pairwise_host: out of pinned host memory"); fail(KSP_E_LIMIT); return; }
             if (total && (rc = ksp_memcpy_d2h(out, d_all, total * sizeof(ksp_edge)))) { ksp_free(out); fail(rc); return; }
@@ -2687,6 +2699,22 @@ int ksp_debug_fktime(unsigned long long* out16, int reset) {
 }
 #endif
 
+}  // extern "C"
+int ksp::pairwise_postings_multi_cc(const uint64_t* key_off, const uint32_t* sources, const uint32_t* key_weights, uint32_t n_keys,
+                                    uint32_t n_sources, const int* devices, int n_devices, ksp_edge** out_edges, uint64_t* n_edges,
+                                    ksp_stats* stats, CcRequest* cc) {
+    if (!out_edges || !n_edges || !devices || (n_keys && (!key_off || !sources))) { set_error("pairwise_postings_host: NULL argument"); return KSP_E_ARG; }
+    const u64 n = n_keys ? key_off[n_keys] : 0;
+    for (u64 i = 0; i < n; ++i)
+        if (sources[i] >= n_sources) { set_error("pairwise_postings_host: source index out of range"); return KSP_E_ARG; }
+    MultiJob job;
+    job.postings = true;
+    job.key_off = key_off; job.sources = sources; job.key_weights = key_weights; job.n_keys = n_keys; job.n_sources = n_sources;
+    job.cc = cc;
+    return run_multi(job, devices, n_devices, out_edges, n_edges, stats);
+}
+extern "C" {
+
 int ksp_pairwise_host_multi(const uint64_t* keys, const uint32_t* weights, const uint64_t* offsets, uint32_t n_sources,
                             const int* devices, int n_devices, ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats) {
     if (!offsets || !out_edges || !n_edges || !devices) { set_error("pairwise_host: NULL argument"); return KSP_E_ARG; }
@@ -2698,14 +2726,7 @@ int ksp_pairwise_host_multi(const uint64_t* keys, const uint32_t* weights, const
 int ksp_pairwise_postings_host_multi(const uint64_t* key_off, const uint32_t* sources, const uint32_t* key_weights,
                                      uint32_t n_keys, uint32_t n_sources, const int* devices, int n_devices,
                                      ksp_edge** out_edges, uint64_t* n_edges, ksp_stats* stats) {
-    if (!out_edges || !n_edges || !devices || (n_keys && (!key_off || !sources))) { set_error("pairwise_postings_host: NULL argument"); return KSP_E_ARG; }
-    const u64 n = n_keys ? key_off[n_keys] : 0;
-    for (u64 i = 0; i < n; ++i)
-        if (sources[i] >= n_sources) { set_error("pairwise_postings_host: source index out of range"); return KSP_E_ARG; }
-    MultiJob job;
-    job.postings = true;
-    job.key_off = key_off; job.sources = sources; job.key_weights = key_weights; job.n_keys = n_keys; job.n_sources = n_sources;
-    return run_multi(job, devices, n_devices, out_edges, n_edges, stats);
+    return ksp::pairwise_postings_multi_cc(key_off, sources, key_weights, n_keys, n_sources, devices, n_devices, out_edges, n_edges, stats, nullptr);
 }
 
 int ksp_pairwise_host(const uint64_t* keys, const uint32_t* weights, const uint64_t* offsets, uint32_t n_sources,

@@ -13,6 +13,17 @@ static thread_local std::string g_error;
 void set_error(const std::string& s) { g_error = s; }
 }  // namespace ksp
 
+namespace ksp {
+int pairwise_postings_multi_cc(const uint64_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, const int*, int, ksp_edge**,
+                               uint64_t*, ksp_stats*, CcRequest*) {
+    set_error("host-only sanitizer build: no HIP engine");
+    return KSP_E_HIP;
+}
+void cc_critical(double, float* vcrit, int* mode) { *vcrit = 0; *mode = 0; }
+void read_names_map(const std::string&, std::vector<std::string>& name_of) { name_of.clear(); }
+void write_cluster_file(const std::string&, double, const std::vector<uint32_t>&, const std::vector<std::string>&) {}
+}  // namespace ksp
+
 extern "C" {
 const char* ksp_last_error(void) { return ksp::g_error.c_str(); }
 void ksp_free(void* p) { std::free(p); }

@@ -51,7 +51,17 @@ namespace {
 typedef std::chrono::high_resolution_clock Clock;
 double since(Clock::time_point t0) { return std::chrono::duration<double>(Clock::now() - t0).count(); }
 
-int run_pairwise(const std::string& prefix, int user_threads) {
+// dist_type != nullptr: also cluster (kSpider cluster, ks_clustering.py:63-137) from the edges while they are on the device
+int run_pairwise(const std::string& prefix, int user_threads, const char* dist_type = nullptr, double cutoff = 0) {
+    int cc_col = 0;
+    if (dist_type) {
+        const std::string dt = *dist_type ? dist_type : "max_cont";
+        cc_col = dt == "min_cont" ? 3 : dt == "avg_cont" ? 4 : dt == "max_cont" ? 5 : 0;
+        if (!cc_col) {
+            ksp::set_error("kspider_pairwise_and_cluster: distance '" + dt + "' is not min_cont, avg_cont or max_cont (ani needs the separate ANI column file: run kspider_cluster)");
+            return KSP_E_ARG;
+        }
+    }
     auto t0 = Clock::now();
     ksp::IndexData ix;
     ksp::load_index(prefix, ix);
@@ -141,8 +151,18 @@ int run_pairwise(const std::string& prefix, int user_threads) {
     uint64_t n_edges = 0;
     ksp_stats st;
     auto t1 = Clock::now();
-    int rc = ksp_pairwise_postings_host_multi(key_off.data(), post_src.data(), key_w.data(), (uint32_t)key_w.size(), N,
-                                              devices.data(), (int)devices.size(), &edges, &n_edges, &st);
+    ksp::CcRequest cc;
+    std::vector<uint32_t> cc_counts, cc_labels;
+    if (cc_col) {
+        cc_counts.resize(N);
+        for (uint32_t i = 0; i < N; ++i) {
+            auto it = kmer_count.find(ids[i]);
+            cc_counts[i] = it == kmer_count.end() ? 0u : it->second;   // (a missing group counts 0 k-mers, as operator[] of the reference yields)
+        }
+        cc.kmer_counts = cc_counts.data(); cc.col = cc_col; cc.cutoff = cutoff; cc.labels = &cc_labels;
+    }
+    int rc = ksp::pairwise_postings_multi_cc(key_off.data(), post_src.data(), key_w.data(), (uint32_t)key_w.size(), N,
+                                             devices.data(), (int)devices.size(), &edges, &n_edges, &st, cc_col ? &cc : nullptr);
     const double t_device = since(t1);
     if (rc != KSP_OK) return rc;
     std::vector<ksp::EdgeRow> rows;
@@ -174,6 +194,49 @@ int run_pairwise(const std::string& prefix, int user_threads) {
     ksp::write_pairwise_tsv(prefix, rows, kmer_count, user_threads);
     if (std::getenv("KSPIDER_VERBOSE"))
         std::cout << "kspider_amd: sources=" << N << " colour-entries=" << E << " pairs=" << rows.size() << std::endl;
+    if (cc_col) {
+        // the cluster file of `kSpider cluster` from the components the device found on the join's own edge records
+        std::vector<std::string> name_of;
+        ksp::read_names_map(prefix, name_of);
+        const uint64_t NN = name_of.size();
+        if (cc_labels.size() != N) cc_labels.assign(N, 0);   // (no edges at all: the device pass did not run)
+        if (n_edges == 0) for (uint32_t i = 0; i < N; ++i) cc_labels[i] = i;
+        // rows that only exist with shared_kmers = 0 (colours of weight 0) are rows of the TSV too: the same test, on the host
+        if (!zero_pairs.empty()) {
+            float vcrit = 0;
+            int mode = 0;
+            ksp::cc_critical(cutoff, &vcrit, &mode);
+            std::vector<uint32_t> parent(cc_labels);
+            auto find = [&](uint32_t v) { while (parent[v] != v) { parent[v] = parent[parent[v]]; v = parent[v]; } return v; };
+            bool merged = false;
+            for (auto& zp : zero_pairs) {
+                auto it = std::lower_bound(rows.begin(), rows.end(), zp, [](const ksp::EdgeRow& r, const std::pair<uint32_t, uint32_t>& k) {
+                    return r.source_1 != k.first ? r.source_1 < k.first : r.source_2 < k.second;
+                });
+                if (it == rows.end() || it->source_1 != zp.first || it->source_2 != zp.second || it->shared != 0) continue;   // (the pair also shares a weighted colour: an ordinary row)
+                const uint32_t a = dense(zp.first), b = dense(zp.second);
+                const float n1 = (float)cc_counts[a], n2 = (float)cc_counts[b];
+                const float c12 = 0.0f / n2, c21 = 0.0f / n1;
+                const float v = cc_col == 3 ? std::min(c12, c21) : cc_col == 5 ? std::max(c12, c21) : (float)((c12 + c21) / 2.0);
+                const bool kept = mode ? v != v : !(v < vcrit);
+                if (!kept) continue;
+                const uint32_t ra = find(a), rb = find(b);
+                if (ra != rb) { parent[std::max(ra, rb)] = std::min(ra, rb); merged = true; }
+            }
+            if (merged) for (uint32_t i = 0; i < N; ++i) cc_labels[i] = find(i);
+        }
+        std::vector<uint32_t> node_label((size_t)NN);
+        for (uint64_t v = 0; v < NN; ++v) node_label[v] = (uint32_t)v;
+        for (uint32_t i = 0; i < N; ++i) {
+            if (cc_labels[i] == i) continue;   // (a root, or a source without a kept edge)
+            const uint64_t a = ids[i], b = ids[cc_labels[i]];
+            if (a < 1 || b < 1 || a > NN || b > NN)
+                throw std::runtime_error("pairwise row names node " + std::to_string(std::max(a, b)) + " but .namesMap has " + std::to_string(NN) + " rows (ids must be 1..N)");
+            node_label[a - 1] = (uint32_t)(b - 1);
+        }
+        ksp::write_cluster_file(prefix, cutoff * 100.0, node_label, name_of);
+        if (std::getenv("KSPIDER_VERBOSE")) std::cout << "kspider_amd: clusters from " << cc.n_kept << " edges that pass the cut" << std::endl;
+    }
     return KSP_OK;
 }
 
@@ -188,6 +251,23 @@ extern "C" int kspider_pairwise(const char* index_prefix, int user_threads) {
         return run_pairwise(index_prefix, user_threads < 1 ? 1 : user_threads);
     } catch (const std::bad_alloc&) {
         ksp::set_error("kspider_pairwise: out of host memory");
+        return KSP_E_LIMIT;
+    } catch (const std::exception& e) {
+        ksp::set_error(e.what());
+        const std::string m = e.what();
+        return m.find("2^32") != std::string::npos ? KSP_E_LIMIT : KSP_E_IO;
+    }
+}
+
+extern "C" int kspider_pairwise_and_cluster(const char* index_prefix, int user_threads, const char* dist_type, double cutoff) {
+    if (!index_prefix) {
+        ksp::set_error("kspider_pairwise_and_cluster: index_prefix is NULL");
+        return KSP_E_ARG;
+    }
+    try {
+        return run_pairwise(index_prefix, user_threads < 1 ? 1 : user_threads, dist_type ? dist_type : "", cutoff);
+    } catch (const std::bad_alloc&) {
+        ksp::set_error("kspider_pairwise_and_cluster: out of host memory");
         return KSP_E_LIMIT;
     } catch (const std::exception& e) {
         ksp::set_error(e.what());

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "ksp_engine_build_postings", "ksp_pairwise_postings_host",
     "ksp_engine_set_profiling", "ksp_engine_phase_times",
     "ksp_pairwise_host_multi", "ksp_pairwise_postings_host_multi",
-    "kspider_cluster", "ksp_components",
+    "kspider_cluster", "ksp_components", "ksp_components_edges", "kspider_pairwise_and_cluster",
 ]
 
 
@@ -209,6 +209,27 @@ def pairwise_postings_host(key_off: np.ndarray, sources: np.ndarray, key_weights
 def cluster(index_prefix: str, dist_type: str = "max_cont", cutoff: float = 0.0) -> None:
     """`kSpider cluster -i PREFIX -d DIST -c CUTOFF` (ks_clustering.py:150-163); components on the GPU."""
     _check(lib().kspider_cluster(os.fsencode(index_prefix), dist_type.encode(), float(cutoff)))
+
+
+def pairwise_and_cluster(index_prefix: str, user_threads: int = 1, dist_type: str = "max_cont", cutoff: float = 0.0) -> None:
+    """`kSpider pairwise` + `kSpider cluster` in one device pass: both TSVs as the two calls would write them, the
+    components taken from the edges while they are in HBM (the pairwise TSV is never read back)."""
+    L = lib()
+    L.kspider_pairwise_and_cluster.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_double]
+    _check(L.kspider_pairwise_and_cluster(os.fsencode(index_prefix), int(user_threads), dist_type.encode(), float(cutoff)))
+
+
+def components_edges(n_nodes: int, d_edges_ptr: int, n_edges: int, d_kmer_counts_ptr: int, dist_col: int, cutoff: float,
+                     device: int = 0) -> np.ndarray:
+    """Components over ksp_edge records in DEVICE memory: an edge counts when its containment column passes the
+    reference's cut (include/kspider_amd.h); label[v] = smallest source index of v's component."""
+    L = lib()
+    L.ksp_components_edges.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int,
+                                       ctypes.c_double, ctypes.c_void_p]
+    out = np.empty(max(1, n_nodes), dtype=np.uint32)
+    _check(L.ksp_components_edges(device, n_nodes, d_edges_ptr or None, n_edges, d_kmer_counts_ptr or None, dist_col, float(cutoff),
+                                  out.ctypes.data))
+    return out[:n_nodes]
 
 
 def components(n_nodes: int, a: np.ndarray, b: np.ndarray, device: int = 0) -> np.ndarray:

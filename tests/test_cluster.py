@@ -145,3 +145,79 @@ def test_components_kernel():
     first = np.full(50_000, n, dtype=np.int64)
     np.minimum.at(first, grp, np.arange(n))
     assert (lab == first[grp]).all()
+
+
+def _names_map(prefix, n):
+    with open(prefix + ".namesMap", "w") as f:
+        f.write(f"{n}\n")
+        for i in range(n):
+            f.write(f"{i + 1} genome_{i + 1}\n")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,mean,cap", [(400, 300, 25), (20000, 300, 150)])
+def test_pairwise_and_cluster_from_hbm_equals_the_two_calls(oracle_lib, tmp_path, n, mean, cap):
+    """kspider_pairwise_and_cluster (components from the join's edge records while they are in HBM) writes the pairwise
+    TSV of kspider_pairwise and the cluster file kspider_cluster derives from that TSV, byte for byte — and the
+    oracle's restatement of ks_clustering.py agrees.  Cut-offs include values that ARE printed containments of rows
+    (the test `text -> float -> x 100 not below cutoff x 100` decided on the device by one critical float), 0 and 1."""
+    from kspider_amd import engine, synth
+    sk = synth.generate("C2", n_sources=n, mean_size=mean, cluster_cap=cap, seed=4321 + n)
+    prefix = str(tmp_path / "ix")
+    oracle_lib.index_from_sketches(prefix, sk.keys, sk.offsets)
+    _names_map(prefix, sk.n_sources)
+    engine.pairwise(prefix, 2)
+    tsv = open(prefix + "_kSpider_pairwise.tsv", "rb").read()
+    rows = tsv.decode().splitlines()[1:]
+    assert len(rows) > (100 if n < 1000 else 500_000)
+    pick = [rows[len(rows) // 3].split("\t"), rows[2 * len(rows) // 3].split("\t")]
+    cases = [("max_cont", 0.2), ("min_cont", 0.05), ("avg_cont", 0.6), ("max_cont", 0.0), ("min_cont", 1.0),
+             ("max_cont", float(pick[0][5])), ("min_cont", float(pick[1][3])), ("avg_cont", float(pick[0][4]))]
+    if n > 1000:
+        cases = cases[:2] + cases[5:]
+    for dist, cutoff in cases:
+        engine.cluster(prefix, dist, cutoff)
+        path = ref_cluster.output_path(prefix, cutoff)
+        want = open(path, "rb").read()
+        os.remove(path)
+        os.remove(prefix + "_kSpider_pairwise.tsv")
+        engine.pairwise_and_cluster(prefix, 2, dist, cutoff)
+        assert open(prefix + "_kSpider_pairwise.tsv", "rb").read() == tsv
+        got = open(path, "rb").read()
+        assert got == want, (dist, cutoff)
+        if n < 1000:
+            os.remove(path)
+            assert got == open(ref_cluster.write_clusters(prefix, dist, cutoff), "rb").read()
+        os.remove(path)
+    with pytest.raises(engine.KspError):
+        engine.pairwise_and_cluster(prefix, 1, "ani", 0.5)
+    with pytest.raises(engine.KspError):
+        engine.pairwise_and_cluster(prefix, 1, "jaccard", 0.5)
+
+
+@pytest.mark.gpu
+def test_components_over_device_edge_records():
+    """ksp_components_edges on the edges ksp_engine_join left in device memory, against a union-find over the rows the
+    reference's test keeps (float32 maths of the TSV writer, '%g' text, Python float x 100 not below cutoff x 100)."""
+    from kspider_amd import engine, synth
+    sk = synth.generate("C2", n_sources=3000, mean_size=400, cluster_cap=60, seed=99)
+    keys_d = engine.DeviceBuffer.from_numpy(sk.keys)
+    cnt_d = engine.DeviceBuffer.from_numpy(sk.sizes.astype(np.uint32))
+    eng = engine.Engine(0)
+    eng.build_blocks(keys_d.ptr.value, sk.offsets)
+    cap = int(eng.edge_bound(0, eng.num_tiles)) + 1
+    ed = engine.DeviceBuffer(cap * 16)
+    m = eng.join(0, eng.num_tiles, ed.ptr.value, cap)
+    ev = ed.to_numpy(engine.EDGE_DTYPE, m)
+    n1 = sk.sizes[ev["source_1"]].astype(np.float32)
+    n2 = sk.sizes[ev["source_2"]].astype(np.float32)
+    sh = ev["shared"].astype(np.float32)
+    c12, c21 = sh / n2, sh / n1
+    cols = {3: np.minimum(c12, c21), 4: ((c12 + c21).astype(np.float64) / 2.0).astype(np.float32), 5: np.maximum(c12, c21)}
+    for col, cutoff in ((5, 0.3), (3, 0.1), (4, 0.5), (5, 0.0), (3, 2.0), (4, float("%g" % cols[4][m // 2]))):
+        text = np.array([float("%g" % v) for v in cols[col]])
+        keep = ~(text * 100 < cutoff * 100)
+        want = _union_find(sk.n_sources, ev["source_1"][keep], ev["source_2"][keep])
+        got = engine.components_edges(sk.n_sources, ed.ptr.value, m, cnt_d.ptr.value, col, cutoff)
+        assert (got == want).all(), (col, cutoff, int(keep.sum()))
+    eng.close()

@@ -125,30 +125,28 @@ def test_join_to_host_in_pieces_equals_one_join(monkeypatch):
     """ksp_engine_join_to_host (the range cut into pieces by the edge bound, piece k copied to host memory under the
     join of piece k + 1) delivers exactly the edges of one ksp_engine_join over the same range — with pieces of one
     tile, of a few tiles, and one piece for everything; a host buffer that is too small reports the full count."""
-    import torch
     sk = synth.generate("C2", n_sources=3000, seed=77)
-    dev = torch.device("cuda", 0)
-    keys_d = torch.from_numpy(sk.keys.view(np.int64)).to(dev)
+    keys_d = engine.DeviceBuffer.from_numpy(sk.keys)
     eng = engine.Engine(0)
-    eng.build_blocks(keys_d.data_ptr(), sk.offsets)
+    eng.build_blocks(keys_d.ptr.value, sk.offsets)
     T = eng.num_tiles
     cap = int(eng.edge_bound(0, T)) + 1
-    ed = torch.empty((cap, 16), dtype=torch.uint8, device=dev)
-    n = eng.join(0, T, ed.data_ptr(), cap)
-    want = np.sort(ed[:n].cpu().numpy().view(engine.EDGE_DTYPE).reshape(-1), order=["source_1", "source_2"])
-    host = torch.empty((n + 8, 16), dtype=torch.uint8).pin_memory()
+    ed = engine.DeviceBuffer(cap * 16)
+    n = eng.join(0, T, ed.ptr.value, cap)
+    want = np.sort(ed.to_numpy(engine.EDGE_DTYPE, n), order=["source_1", "source_2"])
+    host = np.zeros(n + 8, dtype=engine.EDGE_DTYPE)   # (pageable memory works too: pinned memory only makes the copy faster)
     for piece in ("16384", "100000", "100000000"):
         monkeypatch.setenv("KSP_DEBUG_PIECE", piece)
-        host.zero_()
-        m = eng.join_to_host(0, T, host.data_ptr(), host.shape[0])
+        host[:] = 0
+        m = eng.join_to_host(0, T, host.ctypes.data, host.size)
         assert m == n
-        got = np.sort(host[:m].numpy().view(engine.EDGE_DTYPE).reshape(-1), order=["source_1", "source_2"])
+        got = np.sort(host[:m], order=["source_1", "source_2"])
         assert (got == want).all(), piece
     # sub-range, and a buffer that is too small
     t_mid = T // 3
-    n1 = eng.join(0, t_mid, ed.data_ptr(), cap)
-    assert eng.join_to_host(0, t_mid, host.data_ptr(), host.shape[0]) == n1
+    n1 = eng.join(0, t_mid, ed.ptr.value, cap)
+    assert eng.join_to_host(0, t_mid, host.ctypes.data, host.size) == n1
     with pytest.raises(engine.KspError) as ei:
-        eng.join_to_host(0, T, host.data_ptr(), max(1, n // 2))
+        eng.join_to_host(0, T, host.ctypes.data, max(1, n // 2))
     assert ei.value.code == engine.KSP_E_OVERFLOW and ei.value.count == n
     eng.close()
