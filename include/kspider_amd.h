@@ -148,6 +148,14 @@ int ksp_engine_phase_times(const ksp_engine* e, const char** names, float* ms, i
  * The caller guarantees that every source's weights sum to less than 2^32.  Then ksp_engine_join as usual. */
 int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const uint32_t* d_sources,
                               const uint32_t* d_key_weights, uint32_t n_keys, uint32_t n_sources, void* stream);
+/* One SLICE of such an index: any subset of its keys, every key with all its holders (same arguments, the offsets
+ * starting at 0; fewer than 2^30 memberships per slice).  Stops at the source labels; from there the calls of a
+ * key-range slice of sketches apply (ksp_engine_slice_labels, MIN over the slices, ksp_engine_slice_finish, _sizes,
+ * _export, ksp_engine_assemble).  The reference loads an index of any size (src/pairwise.cpp:95-111): kspider_pairwise
+ * cuts one of 2^30 memberships or more into such slices by itself, and with $KSPIDER_DEVICES every device builds the
+ * slice of 1 / n of the colours.                                                                                  */
+int ksp_engine_build_postings_slice(ksp_engine* e, const uint64_t* h_key_off, const uint32_t* d_sources,
+                                    const uint32_t* d_key_weights, uint32_t n_keys, uint32_t n_sources, void* stream);
 
 /* ---- stage 1 sharded over GPUs (one process per GPU) ---------------------------------------
  * Every rank holds the full sketch set; rank `part` of `nparts` sorts and prunes the keys of its

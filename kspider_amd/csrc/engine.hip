@@ -114,6 +114,7 @@ struct ksp_engine {
     const u32 *post_off = nullptr, *post_src = nullptr, *post_w = nullptr;   // postings input of the build in progress (device)
     u32 post_nkeys = 0;
     int slice_phase = 0;          // 1: build_slice done, waiting for ksp_engine_slice_finish
+    bool post_slice = false;      // ... of a postings input (ksp_engine_build_postings_slice): post_off stays valid until the finish
     u64 slice_hdr[4] = {0, 0, 0, 0};   // padded length, distinct keys (U), big postings, block keys
     u32 ncell = ksp::NP;          // fine rank cells per block (power of two)
     bool use_cells = true;        // rank-aligned cell join (KSP_JOIN=window selects the sliding-window merge)
@@ -376,7 +377,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     while ((1u << bbits) < nb) ++bbits;
     size_t tb = 0;
     u64 m = e->n_kept;   // (phase 2: set by phase 1)
-    if (phase == 3) {
+    if (phase == 3 || phase == 4) {   // (4: a slice of a postings input — stops at the labels, ksp_engine_slice_finish runs phase 2)
         m = n;
         e->n_kept = m;
         hipLaunchKernelGGL(k_iota4, dim3(grid_for(N, bs)), dim3(bs), 0, st, iota, order, newidx, label, N);
@@ -397,6 +398,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         } else {
             hipLaunchKernelGGL(k_blk_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, sbound, newidx, e->blk_max.as<u32>(), N);
         }
+        if (phase == 4) return KSP_OK;
     } else if (phase != 2) {
 
     // the hand-written partition (partition_kernels.hip.h) finds the key range on the device and makes the
@@ -1018,7 +1020,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     // ---- the block lists, key by key (see k_key_groups) ------------------------------------------------
     if (!e->key_groups_off && m < (1ull << 32) - KG_CHUNK) {
         const u32 U = (u32)e->h_scal[2];
-        const u32* firstp = phase == 3 ? e->post_off : (const u32*)e->FK.p;   // where each key's entries start (sentinel at U)
+        const bool post_in = phase == 3 || e->post_slice;   // postings input: the key offsets are the caller's
+        const u32* firstp = post_in ? e->post_off : (const u32*)e->FK.p;   // where each key's entries start (sentinel at U)
         u64* gsum = (u64*)KA;                 // per key: groups | masks << 32   (KA: the sorted keys are dead)
         u64* goff = gsum + (U + 2);
         u32* tmp_blk = (u32*)e->KB.p;         // records parked at entry positions (KB: free since the grouping by key)
@@ -1034,7 +1037,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         const u32 chunks = (u32)((m + KG_CHUNK - 1) / KG_CHUNK);
         phase_mark(e, st, "key groups");
         if (!(hand_zeroed && phase == 0)) KSP_HIP(hipMemsetAsync(d_kovf, 0, 8, st));   // (the hand-written partition's build zeroes the whole scalar block at its start)
-        if (phase == 3) KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input only — are visited by no chunk)
+        if (post_in) KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input only — are visited by no chunk)
         hipLaunchKernelGGL((k_key_groups<V, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, crank, firstp, newidx, (u32)m, U,
                            gsum, blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf,
                            std::getenv("KSP_DEBUG_COOP") ? std::max<u32>(KG_COOP, (u32)std::atoi(std::getenv("KSP_DEBUG_COOP"))) : KG_COOP,   // (timing experiments: raise the wave-per-key threshold)
@@ -1143,7 +1146,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     }
     // ---- the block lists by sorting the entries by block -------------------------------------------------
     if (!e->rank1_ok) {   // (the grouping wrote crank[] only: a rank per entry from first[])
-        const u32* fp = phase == 3 ? e->post_off : (const u32*)e->FK.p;
+        const u32* fp = (phase == 3 || e->post_slice) ? e->post_off : (const u32*)e->FK.p;
         hipLaunchKernelGGL(k_rank_fill, dim3(1024), dim3(256), 0, st, fp, (u32)e->h_scal[2], rank1);
         e->rank1_ok = true;
     }
@@ -1583,6 +1586,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     KSP_HIP(hipSetDevice(e->device));
     e->built = false;
     e->slice_ready = false;
+    e->post_slice = false;
     e->sched_on = false; e->collect = false; e->have_bits = false; e->matches_on = false; e->pmask_on = false;   // (nothing of the previous build's work list survives)
     e->act_tid.clear(); e->act_rec.clear();
     for (u32 s = 0; s < n_sources; ++s)
@@ -1685,8 +1689,8 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     return KSP_OK;
 }
 
-int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const uint32_t* d_sources,
-                              const uint32_t* d_key_weights, uint32_t n_keys, uint32_t n_sources, void* stream) {
+static int build_postings_common(ksp_engine* e, const uint64_t* h_key_off, const uint32_t* d_sources, const uint32_t* d_key_weights,
+                                 uint32_t n_keys, uint32_t n_sources, void* stream, const bool slice) {
     if (!e || (n_keys && (!h_key_off || !d_sources))) { set_error("build_postings: NULL argument"); return KSP_E_ARG; }
     hipStream_t st = (hipStream_t)stream;
     KSP_HIP(hipSetDevice(e->device));
@@ -1696,6 +1700,7 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
     e->act_tid.clear(); e->act_rec.clear();
     e->ph_n = 0;
     e->slice_phase = 0;
+    e->post_slice = false;
     const u64 n = n_keys ? h_key_off[n_keys] : 0;
     if (n_keys && h_key_off[0] != 0) { set_error("build_postings: key_off[0] must be 0"); return KSP_E_ARG; }
     for (u32 k = 0; k < n_keys; ++k)
@@ -1725,10 +1730,12 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
     e->h_blk_src.resize((size_t)e->nb + 1);
     for (u32 b = 0; b <= e->nb; ++b) e->h_blk_src[b] = (u32)std::min<u64>(n_sources, (u64)b * TB);
     e->have_bits = false;
+    std::memset(e->slice_hdr, 0, sizeof e->slice_hdr);
     if (n == 0 || e->nb == 0) {   // nothing can intersect
         e->st.n_block_keys = 0;
         e->need32 = false;
-        e->built = true;
+        e->built = !slice;
+        if (slice) e->slice_phase = 1;
         return KSP_OK;
     }
     int rc;
@@ -1756,9 +1763,21 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
     e->post_src = d_sources;
     e->post_w = d_key_weights;
     e->post_nkeys = n_keys;
-    rc = build_dispatch(e, nullptr, nullptr, st, 3);
-    e->post_off = e->post_src = e->post_w = nullptr;
+    rc = build_dispatch(e, nullptr, nullptr, st, slice ? 4 : 3);
+    e->post_src = e->post_w = nullptr;
+    if (!slice) e->post_off = nullptr;
     if (rc) return rc;
+    if (slice) {   // (a slice: up to the source labels; ksp_engine_slice_finish builds its lists once all slices' labels are combined)
+        KSP_HIP(hipMemcpyAsync(e->h_scal + 4, e->scalars.as<u64>() + 4, 8, hipMemcpyDeviceToHost, st));
+        KSP_HIP(hipEventRecord(e->ev[1], st));
+        KSP_HIP(hipStreamSynchronize(st));
+        if ((u32)e->h_scal[4]) { set_error("build_postings: a source index is >= n_sources"); return KSP_E_ARG; }
+        e->h_scal[4] = 0;
+        KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
+        e->post_slice = true;
+        e->slice_phase = 1;
+        return KSP_OK;
+    }
     KSP_HIP(hipMemcpyAsync(e->h_scal + 1, e->scalars.as<u64>() + 1, 64, hipMemcpyDeviceToHost, st));
     KSP_HIP(hipStreamSynchronize(st));
     if ((u32)e->h_scal[4]) { set_error("build_postings: a source index is >= n_sources"); return KSP_E_ARG; }
@@ -1772,6 +1791,20 @@ int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const ui
     KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
     phase_close(e, e->ev[1]);
     return finish_build(e);
+}
+
+int ksp_engine_build_postings(ksp_engine* e, const uint64_t* h_key_off, const uint32_t* d_sources,
+                              const uint32_t* d_key_weights, uint32_t n_keys, uint32_t n_sources, void* stream) {
+    return build_postings_common(e, h_key_off, d_sources, d_key_weights, n_keys, n_sources, stream, false);
+}
+// One slice of an inverted index — any subset of its keys, every key with ALL its holders (so the pruning of stage 1 has
+// nothing to do and every slice's ranks are its own key order) — up to the source labels; then exactly the calls of a
+// key-range slice of sketches: ksp_engine_slice_labels, (MIN over the slices), ksp_engine_slice_finish, _sizes, _export,
+// ksp_engine_assemble.  This is how an index of 2^30 memberships or more goes through (slices built in turn or on several
+// GPUs), and how the devices of $KSPIDER_DEVICES share stage 1 of the reference's own entry point.
+int ksp_engine_build_postings_slice(ksp_engine* e, const uint64_t* h_key_off, const uint32_t* d_sources,
+                                    const uint32_t* d_key_weights, uint32_t n_keys, uint32_t n_sources, void* stream) {
+    return build_postings_common(e, h_key_off, d_sources, d_key_weights, n_keys, n_sources, stream, true);
 }
 
 int ksp_engine_build_blocks(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights,
@@ -2474,11 +2507,11 @@ struct MultiJob {
 
 // The whole job on `nd` devices, one host thread + one engine per device (the reference entry points call this
 // with the devices of $KSPIDER_DEVICES; nd = 1 is the single-GPU path):
-//   stage 1   postings input: every device builds the same lists (that build is deterministic: ranks are the
-//             caller's key order).  Sketch input: device i builds the slice of its 1/nd share of the hash range;
-//             the labels are MIN-combined and the slices exchanged device to device (peer copies over xGMI),
-//             then every device assembles the full lists — the same exchange kspider_amd/dist.py does with
-//             RCCL collectives between processes.
+//   stage 1   device i builds its slice — sketch input: its 1/nd share of the hash range; postings input (the reference's
+//             entry point): 1/nd of the colours (whole keys, cut by memberships) — the labels are MIN-combined and the
+//             slices exchanged device to device (peer copies over xGMI), then every device assembles the full lists:
+//             the same exchange kspider_amd/dist.py does with RCCL collectives between processes.  Inputs of 2^30
+//             entries or more are cut into more slices than there are devices (several workers per device).
 //   stage 2   device i joins the tile range [cuts[i], cuts[i+1]) of equal estimated work (same cuts everywhere:
 //             checked), the edges are gathered to the first device (peer copies), sorted there and copied into
 //             pinned host memory.
@@ -2492,6 +2525,7 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
     // slices of at most ~0.9 * 2^30 entries, built one engine each and assembled — the multi-GPU machinery with several
     // workers per device ($KSP_SLICES forces a slice count: tests).
     std::vector<int> expanded;
+    std::vector<u32> pk_cut;   // postings input in slices: slice s holds the keys [pk_cut[s], pk_cut[s + 1])
     if (!job.postings) {
         u64 want = n < (1ull << 30) ? 1 : n / 900000000ull + 1;   // (equal shares of the hash range: ~equal sizes for hashes)
         if (const char* sl = std::getenv("KSP_SLICES")) want = std::max<u64>(want, (u64)std::max(1, std::atoi(sl)));
@@ -2501,7 +2535,40 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
             devices = expanded.data();
             nd = (int)want;
         }
+    } else {
+        // An inverted index (the reference's colour -> sources map, src/pairwise.cpp:95-111, which has no size limit): slices
+        // of whole keys with fewer than 2^30 memberships each — one per device of the job, more (built side by side on the
+        // devices there are) when the index is larger than that, $KSP_SLICES forces a count (tests).  Every device then
+        // builds 1 / nd of the colours instead of all of them.
+        u64 want = n < (1ull << 30) ? 1 : n / 900000000ull + 1;
+        if (const char* sl = std::getenv("KSP_SLICES")) want = std::max<u64>(want, (u64)std::max(1, std::atoi(sl)));
+        want = std::max<u64>(want, (u64)nd);
+        if (want > (u64)job.n_keys && n < (1ull << 30)) want = 1;   // (fewer colours than slices: every device builds the few there are, the tiles are still shared)
+        if (want > 1) {
+            if (want > 64) { set_error("pairwise: more than 2^35 colour memberships"); return KSP_E_LIMIT; }
+            if (want > (u64)nd) {
+                for (u64 i = 0; i < want; ++i) expanded.push_back(devices[i % (u64)nd]);
+                devices = expanded.data();
+                nd = (int)want;
+            }
+            pk_cut.assign((size_t)nd + 1, 0);
+            u32 k = 0;
+            for (int sidx = 1; sidx < nd; ++sidx) {   // cut where the memberships reach s / nd of all (whole keys, no empty slice)
+                const u64 goal = n / (u64)nd * (u64)sidx;
+                while (k < job.n_keys && job.key_off[k] < goal) ++k;
+                k = std::max<u32>(k, pk_cut[(size_t)sidx - 1] + 1);
+                k = std::min<u32>(k, job.n_keys - (u32)(nd - sidx));
+                pk_cut[(size_t)sidx] = k;
+            }
+            pk_cut[(size_t)nd] = job.n_keys;
+            for (int sidx = 0; sidx < nd; ++sidx)
+                if (job.key_off[pk_cut[(size_t)sidx + 1]] - job.key_off[pk_cut[(size_t)sidx]] >= (1ull << 30)) {
+                    set_error("pairwise: one colour range holds 2^30 memberships or more (a single colour that large?)");
+                    return KSP_E_LIMIT;
+                }
+        }
     }
+    const bool sliced = job.postings ? !pk_cut.empty() : nd > 1;
     struct Dev {
         ksp_engine* e = nullptr;
         void *d_a = nullptr, *d_b = nullptr;      // keys + weights, or sources + key weights
@@ -2535,7 +2602,21 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
         int owner = i;   // the first worker on my device uploads the input; the others use its copy
         for (int j = 0; j < i; ++j)
             if (devices[j] == device) { owner = j; break; }
-        if (!bar.failed_hint() && n && owner == i) {
+        if (job.postings && sliced) owner = i;   // (every worker uploads its own slice of the index)
+        std::vector<u64> my_off;                 // key offsets of my slice, from 0
+        u32 my_keys = 0;
+        if (!bar.failed_hint() && job.postings && sliced) {
+            const u32 k0 = pk_cut[(size_t)i], k1 = pk_cut[(size_t)i + 1];
+            my_keys = k1 - k0;
+            my_off.resize((size_t)my_keys + 1);
+            const u64 e0 = job.key_off[k0];
+            for (u32 k = 0; k <= my_keys; ++k) my_off[k] = job.key_off[k0 + k] - e0;
+            const u64 ne = my_off[my_keys];
+            if ((rc = ksp_device_malloc(device, ne * 4, &D.d_a)) || (rc = ksp_memcpy_h2d(D.d_a, job.sources + e0, ne * 4))) fail(rc);
+            if (!rc && job.key_weights &&   // (allocated even for an empty slice: a non-NULL weight array is what makes a build weighted)
+                ((rc = ksp_device_malloc(device, (u64)my_keys * 4, &D.d_b)) || (rc = ksp_memcpy_h2d(D.d_b, job.key_weights + k0, (u64)my_keys * 4))))
+                fail(rc);
+        } else if (!bar.failed_hint() && n && owner == i) {
             if (job.postings) {
                 if ((rc = ksp_device_malloc(device, n * 4, &D.d_a)) || (rc = ksp_memcpy_h2d(D.d_a, job.sources, n * 4))) fail(rc);
                 if (!rc && job.key_weights &&
@@ -2550,7 +2631,9 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
         if (nd > 1 && sync_point()) return;   // (the uploads are complete: ksp_memcpy_h2d is synchronous)
         if (owner != i) { D.d_a = dev[(size_t)owner].d_a; D.d_b = dev[(size_t)owner].d_b; D.borrowed = true; }
         if (!bar.failed_hint()) {
-            if (job.postings)
+            if (job.postings && sliced)
+                rc = ksp_engine_build_postings_slice(D.e, my_off.data(), (const u32*)D.d_a, (const u32*)D.d_b, my_keys, N, nullptr);
+            else if (job.postings)
                 rc = ksp_engine_build_postings(D.e, job.key_off, (const u32*)D.d_a, (const u32*)D.d_b, job.n_keys, N, nullptr);
             else if (nd == 1)
                 rc = ksp_engine_build_blocks(D.e, (const u64*)D.d_a, (const u32*)D.d_b, job.offsets, N, 0, nullptr);
@@ -2558,7 +2641,7 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
                 rc = ksp_engine_build_slice(D.e, (const u64*)D.d_a, (const u32*)D.d_b, job.offsets, N, 0, (u32)i, (u32)nd, nullptr);
             if (rc) fail(rc);
         }
-        if (!job.postings && nd > 1) {   // the slices become the full lists on every device
+        if (sliced) {   // the slices become the full lists on every device
             // common source order: element-wise MIN of the devices' labels
             if (!bar.failed_hint() && N) {
                 lab_dev[(size_t)i].resize(N);
@@ -2584,7 +2667,7 @@ static int run_multi(const MultiJob& job, const int* devices, int nd, ksp_edge**
             u64 lstride = 4, bigstride = 1;
             for (int j = 0; j < nd; ++j) { lstride = std::max(lstride, all_sizes[(size_t)j * 4]); bigstride = std::max(bigstride, all_sizes[(size_t)j * 4 + 2]); }
             const u32 nb = D.e->nb;   // (the same on every device: a function of the source count)
-            const bool weighted = job.weights != nullptr;
+            const bool weighted = job.postings ? job.key_weights != nullptr : job.weights != nullptr;
             const size_t bytes[6] = {lstride * 4, lstride * 4, weighted ? lstride * 4 : 0, ((size_t)nb + 1) * 4, ((size_t)nb + 1) * 4, bigstride * 16};
             for (int q = 0; q < 6 && !rc; ++q) {
                 if (!bytes[q]) continue;

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "kspider_pairwise_sigs", "kspider_pairwise_bins",
     "ksp_engine_build_slice", "ksp_engine_slice_sizes", "ksp_engine_slice_export", "ksp_engine_assemble",
     "ksp_engine_edge_bound", "ksp_engine_slice_labels", "ksp_engine_slice_finish", "ksp_engine_balanced_cuts",
-    "ksp_engine_build_postings", "ksp_pairwise_postings_host",
+    "ksp_engine_build_postings", "ksp_engine_build_postings_slice", "ksp_pairwise_postings_host",
     "ksp_engine_set_profiling", "ksp_engine_phase_times",
     "ksp_pairwise_host_multi", "ksp_pairwise_postings_host_multi",
     "kspider_cluster", "ksp_components", "ksp_components_edges", "kspider_pairwise_and_cluster",
