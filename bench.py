@@ -108,7 +108,14 @@ def cpu_baseline(sk, sample_sources: int, gpu_edges: np.ndarray | None = None) -
         why = ("; more threads are not faster: every update takes one of 4 096 std::mutex locks (src/pairwise.cpp:22-27), "
                "a thread that finds its submap locked sleeps in the kernel (futex) and the pairs of a cluster keep "
                "hitting the same submaps")
+    dropin = None
+    if os.environ.get("KSP_BENCH_DROPIN", "1") == "1":
+        try:
+            dropin = dropin_end_to_end(oracle, sub, co, src, w, best["cores"])
+        except Exception as ex:   # (never takes the bench line down)
+            dropin = {"error": str(ex)}
     return {
+        "dropin_s": dropin,
         "value": best["value"], "unit": "pairs/s", "cores": best["cores"], "kind": "port",
         "sample": f"first {n} of the workload's sources ({int(sub.offsets[-1])} hashes, {len(w)} colours, "
                   f"{n_updates} map updates, {n_edges} non-zero pairs); accumulate region only "
@@ -116,6 +123,50 @@ def cpu_baseline(sk, sample_sources: int, gpu_edges: np.ndarray | None = None) -
                   f"host has {avail} usable cores; best of the thread sweep in `runs`{why}",
         "secs": best["secs"], "runs": runs, "edges_equal_gpu": verified,
     }
+
+
+def dropin_end_to_end(oracle, sub, co, src, w, cpu_threads: int) -> dict:
+    """The reference's actual API end to end on index files (part of the CPU-baseline leg: the oracle writes the three
+    .bin files of the same sample and runs its restatement of kSpider::pairwise on them): `pairwise PREFIX T` of
+    this library — index load, device round trip, TSV — next to the restated reference, TSVs compared byte for byte."""
+    import shutil
+    import subprocess
+    import tempfile
+    from kspider_amd import engine
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="ksp_dropin_", dir=base)
+    try:
+        prefix = os.path.join(d, "idx")
+        oracle.write_index(prefix, co, src, w, None, np.diff(sub.offsets.astype(np.int64)).astype(np.uint32))
+        exe = os.path.join(os.path.dirname(engine.LIB_PATH), "pairwise")
+        threads = min(64, len(os.sched_getaffinity(0)))
+        env = dict(os.environ, KSPIDER_VERBOSE="1")
+        out = None
+        for _ in range(2):   # (the first run pays the GPU start-up of a fresh process; the second is reported)
+            t = time.perf_counter()
+            out = subprocess.run([exe, prefix, str(threads)], capture_output=True, text=True, check=True, env=env)
+            wall = time.perf_counter() - t
+        got = open(prefix + "_kSpider_pairwise.tsv", "rb").read()
+        phases = {}
+        for line in out.stdout.splitlines():
+            for key, name in (("mapping colors to groups:", "load_s"), ("kmer counting:", "kmer_counts_s"),
+                              ("pairwise hashmap construction:", "construction_s")):
+                if line.startswith(key):
+                    phases[name] = float(line.split(":")[1].split()[0])
+            if "device round trip" in line:
+                phases["device_round_trip_s"] = float(line.split("device round trip")[1].split()[0])
+        t = time.perf_counter()
+        secs, n_rows, _ = oracle.ref_pairwise(prefix, cpu_threads)
+        cpu_wall = time.perf_counter() - t
+        want = open(prefix + "_kSpider_pairwise.tsv", "rb").read()
+        return {"wall_s": wall, **phases, "tsv_bytes": len(got), "host_threads": threads,
+                "index_bytes": sum(os.path.getsize(prefix + f) for f in ("_color_to_sources.bin", "_color_count.bin", "_groupID_to_kmerCount.bin")),
+                "cpu_restatement_wall_s": cpu_wall, "cpu_restatement_accumulate_s": secs, "cpu_threads": cpu_threads,
+                "tsv_identical": bool(got == want), "rows": int(n_rows),
+                "note": "wall_s: the whole `pairwise PREFIX T` process of this library (start-up, index load, device, TSV); "
+                        "construction_s: the region the reference times as 'pairwise hashmap construction'"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def edge_checksum(ev: np.ndarray) -> int:
@@ -483,6 +534,7 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(sk, args.cpu_sample, final_edges)
                 out["config"]["verified_against_cpu_baseline"] = out["cpu_baseline"].pop("edges_equal_gpu")
+                out["dropin_s"] = out["cpu_baseline"].pop("dropin_s")
             except Exception as ex:  # the baseline must never take the bench line down
                 out["cpu_baseline"] = {"value": None, "unit": "pairs/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {ex}"}

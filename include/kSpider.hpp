@@ -19,8 +19,11 @@
 
 namespace kSpider {
 
-// Device = $KSPIDER_DEVICE (default 0).  user_threads: host threads used for formatting
-// the TSV (the reference uses it for its OpenMP accumulate loop).
+// Device = $KSPIDER_DEVICE (default 0), or the devices of $KSPIDER_DEVICES ("0,1,2,...": every device builds the
+// block lists of 1 / n of the colours and joins 1 / n of the tiles; the edges meet on the first device over xGMI).
+// An index of 2^30 colour memberships or more is cut into slices by itself (the reference has no size limit,
+// src/pairwise.cpp:95-111).  user_threads: host threads used for formatting the TSV (the reference uses it for its
+// OpenMP accumulate loop).
 void pairwise(std::string index_prefix, int user_threads);
 
 }  // namespace kSpider

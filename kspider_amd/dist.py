@@ -1,9 +1,10 @@
 """One-process-per-GPU sharding of the pair space and the final edge gather.
 
 The N x N pair space is cut into 128 x 128 tiles (block pairs); the tiles of the upper
-triangle, in row-major order, are split into `world_size` contiguous ranges of equal tile
-count — a row-block-wise shard with equal triangular area.  Tiles are
-independent, so the only exchange step is the final variable-length gather of the edge
+triangle, in row-major order, are split into `world_size` contiguous ranges of equal
+ESTIMATED WORK (ksp_engine_balanced_cuts: equal numbers of work-list shares — equal tile
+counts would be badly unbalanced now that the work sits on the diagonal).  Tiles
+are independent, so the only exchange step is the final variable-length gather of the edge
 lists to rank 0: a batch of point-to-point sends (ncclSend/ncclRecv inside one group call
 with the "nccl" backend = RCCL over xGMI; the same code runs on "gloo" for CPU tests).
 """
@@ -17,7 +18,8 @@ EDGE_BYTES = 16  # struct ksp_edge
 
 
 def tile_range(num_tiles: int, world_size: int, rank: int) -> tuple[int, int]:
-    """Contiguous slice [t0, t1) of the row-major tile list owned by `rank`."""
+    """(tests only: equal tile COUNTS; the bench and the engine cut by estimated work, Engine.balanced_cuts)
+    Contiguous slice [t0, t1) of the row-major tile list owned by `rank`."""
     return (num_tiles * rank) // world_size, (num_tiles * (rank + 1)) // world_size
 
 
