@@ -344,15 +344,17 @@ def main():
             stats["edges"] = int(allv.shape[0]) if rank == 0 else cnt
             stats["last_buf"] = buf
 
-    def collect(record_join: bool):
-        """Count of the launched join (it has finished whenever a later build on the same stream has returned)."""
+    def collect(record_join: bool, known_count=None):
+        """Count of the launched join (it has finished whenever a later build on the same stream has returned);
+        known_count: ksp_engine_step_launch has collected it already."""
         job = pending[0]
         if job is None:
             return None
         pending[0] = None
-        job["cnt"] = eng.join_wait()
+        job["cnt"] = eng.join_wait() if known_count is None else known_count
         if job["record"] and record_join:
-            stats["ms_join"] += eng.ms_join()   # (one field: this sits between a build and the launch of its join)
+            # (one field: this sits between a build and the launch of its join)
+            stats["ms_join"] += eng.ms_join() if known_count is None else eng.prev_ms_join
         return job
 
     def step(record: bool):
@@ -361,24 +363,30 @@ def main():
         # stream) while the device is already busy — the device does not wait for the host between a join and the next
         # build.  Every step still takes its tile range and buffer sizes from ITS OWN build (the engine's source order,
         # and with it the tile numbering, differs from build to build).
-        if sharded:   # sharded by hash range + all-gather of the block-list slices: every rank assembles the same lists
-            stats["xchg_bytes"] = kdist.build_blocks_sharded(eng, keys_d.data_ptr(), sk.offsets, world, rank, dev,
-                                                             stream=stream.cuda_stream)
-        else:
-            eng.build_blocks(keys_d.data_ptr(), sk.offsets, stream=stream.cuda_stream)
-        prev = collect(True)        # (the previous join ran in front of this build: the wait returns at once)
-        cuts = eng.balanced_cuts(world)
-        t0, t1 = cuts[rank], cuts[rank + 1]
         buf = step_no[0] & 1
         step_no[0] += 1
         if copied[buf] is not None:
-            copied[buf].synchronize()       # the copy that last read this buffer pair (two steps ago)
-        need = int(min(eng.edge_bound(t0, t1), 1 << 27)) + 1
-        if edges_dd[buf] is None or edges_dd[buf].shape[0] < need:
-            edges_dd[buf] = torch.empty((need + need // 8, 16), dtype=torch.uint8, device=dev)
-            stats["regrown"] += 1
+            copied[buf].synchronize()       # the copy that last read this buffer pair (two steps ago; long done)
+        launched = False
+        if sharded:   # sharded by hash range + all-gather of the block-list slices: every rank assembles the same lists
+            stats["xchg_bytes"] = kdist.build_blocks_sharded(eng, keys_d.data_ptr(), sk.offsets, world, rank, dev,
+                                                             stream=stream.cuda_stream)
+            cuts = eng.balanced_cuts(world)
+            t0, t1 = cuts[rank], cuts[rank + 1]
+            need = int(min(eng.edge_bound(t0, t1), 1 << 27)) + 1
+        else:
+            # build + cuts + bound + join launch in one call of the library: nothing of Python between a build and its join
+            have = edges_dd[buf].shape[0] if edges_dd[buf] is not None else 0
+            t0, t1, bound, launched, prev_cnt = eng.step_launch(keys_d.data_ptr(), sk.offsets, rank, world,
+                                                                edges_dd[buf].data_ptr() if have else 0, have, stream=stream.cuda_stream)
+            need = int(min(bound, 1 << 27)) + 1
+        prev = collect(True, prev_cnt if not sharded else None)   # (the previous join ran in front of this build: the wait returns at once)
+        if not launched:
+            if edges_dd[buf] is None or edges_dd[buf].shape[0] < need:
+                edges_dd[buf] = torch.empty((need + need // 8, 16), dtype=torch.uint8, device=dev)
+                stats["regrown"] += 1
+            eng.join_launch(t0, t1, edges_dd[buf].data_ptr(), edges_dd[buf].shape[0], stream=stream.cuda_stream)
         edges_d = edges_dd[buf]
-        eng.join_launch(t0, t1, edges_d.data_ptr(), edges_d.shape[0], stream=stream.cuda_stream)
         ready = torch.cuda.Event()
         ready.record(stream)
         pending[0] = {"buf": buf, "edges_d": edges_d, "record": record, "ready": ready, "cnt": 0}
@@ -411,6 +419,11 @@ def main():
         step(False)
     drain()
     stats["regrown"] = 0
+    # (no collector pause inside the timed region: one step in ~50 took 9 ms longer with the cyclic GC left on, on an
+    #  otherwise idle box; every step allocates a few event objects)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t_start = time.perf_counter()
     trace = os.environ.get("KSP_BENCH_TRACE") == "1"   # (diagnostic: host time of every step's calls, on stderr)
@@ -422,6 +435,7 @@ def main():
     drain()                 # (the last step's count, gather and D2H: inside the timed region)
     barrier()
     elapsed = time.perf_counter() - t_start
+    gc.enable()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

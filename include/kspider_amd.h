@@ -123,6 +123,19 @@ int ksp_engine_join_wait(ksp_engine* e, uint64_t* h_count);
  * before _launch — the bound is exact enough to allocate by — and treat KSP_E_OVERFLOW from _wait as "this step's
  * result is incomplete, run the step again".                                                                     */
 
+/* One step of a pipelined caller in one call: ksp_engine_build_blocks, the tile range of rank `part` of `nparts`
+ * (ksp_engine_balanced_cuts; returned in range[0..1]), its edge bound (*bound) and ksp_engine_join_launch on that range
+ * into d_edges — nothing between the build and the launch of its join but the cutting of the work list.
+ * KSP_E_OVERFLOW: *bound + 1 > capacity, nothing was launched (grow the buffer, then ksp_engine_join_launch).
+ * A join launched on this engine before the call (the previous step's) is collected on the way — it ran in front of
+ * this build on the stream: *prev_count / *prev_status are what ksp_engine_join_wait would have returned for it,
+ * *prev_ms_join (may be NULL) its kernel time.
+ * Collect the join launched here with ksp_engine_join_wait, or with the next ksp_engine_step_launch.             */
+int ksp_engine_step_launch(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights, const uint64_t* h_offsets,
+                           uint32_t n_sources, int key_bits, uint32_t part, uint32_t nparts, ksp_edge* d_edges,
+                           uint64_t capacity, uint64_t range[2], uint64_t* bound, uint64_t* prev_count, int* prev_status,
+                           float* prev_ms_join, void* stream);
+
 /* Join tiles [tile_begin, tile_end) and deliver the edges in HOST memory (h_edges: `capacity` edges, pinned memory
  * for full PCIe rate): the range is cut into pieces by the edge bound, piece k + 1 is joined while piece k is copied
  * on a stream of the engine's own.  For results of hundreds of MB (100k genomes: 45 M pairs), whose copy would

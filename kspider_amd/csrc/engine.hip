@@ -1040,7 +1040,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         if (post_in) KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input only — are visited by no chunk)
         hipLaunchKernelGGL((k_key_groups<V, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, crank, firstp, newidx, (u32)m, U,
                            gsum, blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf,
-                           std::getenv("KSP_DEBUG_COOP") ? std::max<u32>(KG_COOP, (u32)std::atoi(std::getenv("KSP_DEBUG_COOP"))) : KG_COOP,   // (timing experiments: raise the wave-per-key threshold)
+                           std::getenv("KSP_DEBUG_COOP") ? std::max<u32>(KG_COOP_MIN, (u32)std::atoi(std::getenv("KSP_DEBUG_COOP"))) : KG_COOP,   // (timing experiments: the wave-per-key threshold)
                            huge_list);
         if (huge_list)
             hipLaunchKernelGGL((k_key_groups_huge<V, W>), dim3(256), dim3(256), 0, st, VA, firstp, newidx, nb, gsum, blk0,
@@ -1675,7 +1675,13 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
         if ((rc = stage_block_tables(e, st))) return rc;
     }
     KSP_HIP(hipEventRecord(e->ev[1], st));
-    KSP_HIP(hipStreamSynchronize(st));
+    // (polling the event instead of a blocking wait: the join cannot be cut into shares before the build's tables have
+    //  landed, and waking a blocked host thread is tens of microseconds of device idle time per step)
+    {
+        hipError_t qe;
+        while ((qe = hipEventQuery(e->ev[1])) == hipErrorNotReady) {}
+        KSP_HIP(qe);
+    }
     KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
     phase_close(e, e->ev[1]);
     e->st.key_bits = e->key_bits;
@@ -2349,6 +2355,36 @@ int ksp_engine_join_to_host(ksp_engine* e, uint64_t tile_begin, uint64_t tile_en
         return KSP_E_OVERFLOW;
     }
     return KSP_OK;
+}
+
+// One step of a pipelined caller in ONE call: stage 1, this rank's tile range of equal estimated work, and — when its edge
+// bound fits the caller's buffer — the join launched right behind it.  What bench.py did from Python between a build and
+// the launch of its join (cuts, bound, buffer check: ~50 us during which the device had nothing to do) happens here.
+// KSP_E_OVERFLOW: the bound (in *bound) exceeds `capacity`; nothing was launched — grow the buffer and call
+// ksp_engine_join_launch(e, range[0], range[1], ...) yourself.
+int ksp_engine_step_launch(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights, const uint64_t* h_offsets, uint32_t n_sources,
+                           int key_bits, uint32_t part, uint32_t nparts, ksp_edge* d_edges, uint64_t capacity, uint64_t range[2],
+                           uint64_t* bound, uint64_t* prev_count, int* prev_status, float* prev_ms_join, void* stream) {
+    if (!range || !bound || !prev_count || !prev_status || nparts == 0 || part >= nparts) { set_error("step_launch: bad argument"); return KSP_E_ARG; }
+    *prev_count = 0;
+    *prev_status = KSP_OK;
+    if (prev_ms_join) *prev_ms_join = 0;
+    const bool had_join = e && e->join_pending;
+    const u64 had_cap = e ? e->join_cap : 0;
+    int rc = ksp_engine_build_blocks(e, d_keys, d_weights, h_offsets, n_sources, key_bits, stream);
+    if (rc) return rc;
+    if (had_join) {   // the join launched before this build ran in front of it on the stream: its count is there
+        e->join_pending = true;
+        e->join_cap = had_cap;
+        *prev_status = ksp_engine_join_wait(e, prev_count);
+        if (prev_ms_join) *prev_ms_join = e->st.ms_join;
+    }
+    std::vector<u64> cuts((size_t)nparts + 1);
+    if ((rc = ksp_engine_balanced_cuts(e, nparts, cuts.data()))) return rc;
+    range[0] = cuts[part]; range[1] = cuts[(size_t)part + 1];
+    *bound = ksp_engine_edge_bound(e, range[0], range[1]);
+    if (*bound + 1 > capacity) { set_error("step_launch: the edge bound exceeds the buffer (nothing launched)"); return KSP_E_OVERFLOW; }
+    return ksp_engine_join_launch(e, range[0], range[1], d_edges, capacity, stream);
 }
 
 int ksp_engine_set_profiling(ksp_engine* e, int on) {

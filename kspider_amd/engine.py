@@ -22,7 +22,7 @@ KSP_OK, KSP_E_ARG, KSP_E_HIP, KSP_E_IO, KSP_E_OVERFLOW, KSP_E_LIMIT = range(6)
 ABI_SYMBOLS = [
     "ksp_last_error", "ksp_device_count", "ksp_engine_create", "ksp_engine_destroy",
     "ksp_engine_build_blocks", "ksp_engine_num_tiles", "ksp_engine_tile_pairs", "ksp_engine_join",
-    "ksp_engine_join_launch", "ksp_engine_join_wait", "ksp_engine_join_to_host",
+    "ksp_engine_join_launch", "ksp_engine_join_wait", "ksp_engine_join_to_host", "ksp_engine_step_launch",
     "ksp_engine_get_stats", "ksp_device_malloc", "ksp_device_free", "ksp_memcpy_h2d", "ksp_memcpy_d2h",
     "ksp_pairwise_host", "ksp_free", "kspider_pairwise", "ksp_index_info", "ksp_format_float",
     "kspider_pairwise_sigs", "kspider_pairwise_bins",
@@ -279,6 +279,33 @@ class Engine:
         _check(lib().ksp_engine_build_blocks(self._h, d_keys_ptr or None, d_weights_ptr or None,
                                              h_offsets.ctypes.data, h_offsets.size - 1, key_bits, stream or None))
 
+    def step_launch(self, d_keys_ptr: int, h_offsets: np.ndarray, part: int, nparts: int, d_edges_ptr: int, capacity: int,
+                    stream: int = 0):
+        """build_blocks + this rank's tile range + join_launch on it in one call (include/kspider_amd.h).  Returns
+        (t0, t1, bound, launched, prev_count); launched False: the bound does not fit `capacity`, call join_launch(t0, t1, ...);
+        prev_count: the count of the join that was pending on this engine (None: there was none)."""
+        h_offsets = np.ascontiguousarray(h_offsets, dtype=np.uint64)
+        self._off = h_offsets
+        L = lib()
+        L.ksp_engine_step_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                             ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        rng = (ctypes.c_uint64 * 2)()
+        bound = ctypes.c_uint64(0)
+        prev = ctypes.c_uint64(0)
+        prev_rc = ctypes.c_int(0)
+        prev_ms = ctypes.c_float(0)
+        had = bool(self._join_in_flight) if hasattr(self, "_join_in_flight") else False
+        rc = L.ksp_engine_step_launch(self._h, d_keys_ptr or None, None, h_offsets.ctypes.data, h_offsets.size - 1, 0, part, nparts,
+                                      d_edges_ptr or None, capacity, rng, ctypes.byref(bound), ctypes.byref(prev), ctypes.byref(prev_rc),
+                                      ctypes.byref(prev_ms), stream or None)
+        self.prev_ms_join = float(prev_ms.value)
+        _check(prev_rc.value)
+        self._join_in_flight = rc == KSP_OK
+        if rc != KSP_E_OVERFLOW:
+            _check(rc)
+        return int(rng[0]), int(rng[1]), int(bound.value), rc == KSP_OK, (int(prev.value) if had else None)
+
     def build_postings(self, h_key_off: np.ndarray, d_sources_ptr: int, d_key_weights_ptr: int, n_sources: int,
                        stream: int = 0):
         """Stage 1 from an inverted index: key k is held by d_sources[key_off[k]:key_off[k+1]] (device uint32)."""
@@ -351,9 +378,11 @@ class Engine:
     def join_launch(self, t0: int, t1: int, d_edges_ptr: int, capacity: int, stream: int = 0) -> None:
         """Queue the join on `stream` and return; join_wait() collects the count (see include/kspider_amd.h)."""
         _check(lib().ksp_engine_join_launch(self._h, t0, t1, d_edges_ptr or None, capacity, ctypes.c_void_p(stream)))
+        self._join_in_flight = True
 
     def join_wait(self) -> int:
         cnt = ctypes.c_uint64(0)
+        self._join_in_flight = False
         _check(lib().ksp_engine_join_wait(self._h, ctypes.byref(cnt)))
         return int(cnt.value)
 
