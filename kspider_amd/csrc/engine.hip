@@ -365,7 +365,13 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     // the label pass over the kept keys (first[] = where each key's entries start); KB is free whenever it runs
     auto run_label = [&](const u32* firstp, const u32 n_keys, const u64 kept, const u64* scal_dev = nullptr) {
         const u32 skip = label_sampling(e, kept);
-        const int ls = e->KB.bytes >= (size_t)N * 128 ? 5 : 0;
+        // labels on memory lines of their own while they are lowered — for source sets whose labels would otherwise share a
+        // few hundred lines (10 000 sources: 98 -> 39 us).  A large set spreads its atomics by itself, and 128 bytes per
+        // source turn every look at a label into a line of its own from HBM: 1 M sources, k_label 2.46 ms and 17 GB fetched
+        // (a quarter of that build) against a 4 MB table that stays in L2.
+        u32 spread_max = 262144;   // (100 000 sources: still 1 % faster spread; 1 M: 0.9 ms slower)
+        if (const char* sv = std::getenv("KSP_DEBUG_LABEL_SPREAD")) spread_max = (u32)std::atoi(sv);   // (timing experiments: sources up to which the labels are spread)
+        const int ls = N <= spread_max && e->KB.bytes >= (size_t)N * 128 ? 5 : 0;
         u32* lab = ls ? (u32*)e->KB.p : label;
         if (ls) hipLaunchKernelGGL(k_label_spread, dim3(grid_for(N, bs)), dim3(bs), 0, st, lab, ls, N);
         hipLaunchKernelGGL((k_label<V>), dim3(grid_for(n_keys / (skip + 1) + 1, bs)), dim3(bs), 0, st, VA, firstp, lab, ls,
@@ -714,6 +720,14 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             } else {
             hipLaunchKernelGGL(k_part_src, dim3(grid_for((u64)hp_nchunks + 1, bs)), dim3(bs), 0, st, d_off, N, hp_nchunks, hp_src, scal,
                                nbuckets);
+            // (short sources — fewer than two consecutive entries per level-1 bucket on average — are ordered in LDS before
+            //  they are written: see k_part1; KSP_DEBUG_PART_SORTED=0 / 1 forces the choice: timing experiments, tests)
+            bool p1_sorted = N && n / N < 2ull * hp_nb1;
+            if (const char* sv = std::getenv("KSP_DEBUG_PART_SORTED")) p1_sorted = std::atoi(sv) != 0;
+            if (p1_sorted)
+                hipLaunchKernelGGL((k_part1<V, true>), dim3(hp_nchunks), dim3(P1_THREADS), 0, st, d_keys, d_off, N, (u32)nw, scal,
+                                   hp_pb2 + hp_pbm, hp_pb2, nbuckets - 1, hp_a, hp_src, e->PK.as<u64>(), e->PT.as<V>(), e->PD.as<u8>());
+            else
             hipLaunchKernelGGL((k_part1<V>), dim3(hp_nchunks), dim3(P1_THREADS), 0, st, d_keys, d_off, N, (u32)nw, scal,
                                hp_pb2 + hp_pbm, hp_pb2, nbuckets - 1, hp_a, hp_src, e->PK.as<u64>(), e->PT.as<V>(), e->PD.as<u8>());
             }
@@ -1118,11 +1132,11 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                 tb = 0;
                 KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
                 KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
-                if (nb <= BRP_MAX) {
+                if (nb <= 1024) {   // (one workgroup while the serial layout of the starts is short: 7 813 blocks took 0.32 ms in it)
                     hipLaunchKernelGGL(k_blk_raw_pos, dim3(1), dim3(1024), 0, st, sblk, (u32)e->h_scal[1], blk_raw, blk_pos, scal, nb);
                 } else {
                     hipLaunchKernelGGL(k_blk_raw_groups, dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, sblk, (u32)e->h_scal[1], blk_raw, nb);
-                    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, blk_raw, blk_pos, scal, nb);
+                    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(1024), 0, st, blk_raw, blk_pos, scal, nb);
                 }
                 hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
                 hipLaunchKernelGGL((k_place_groups<W>), dim3(grid_for(K, bs)), dim3(bs), 0, st, sblk, sval, blk_raw, blk_pos, wkey,
@@ -1176,7 +1190,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     // an order of magnitude below the entry count: one 8-byte read-back pays for itself)
     KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 8, hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL((k_blk_raw<V>), dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, T, estart, scal, blk_raw, nb, m);
-    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, blk_raw, blk_pos, scal, nb);
+    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(1024), 0, st, blk_raw, blk_pos, scal, nb);
     hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
     KSP_HIP(hipStreamSynchronize(st));
     const u64 K = std::max<u64>(1, e->h_scal[1]);
@@ -1869,7 +1883,7 @@ int ksp_engine_slice_finish(ksp_engine* e, const uint32_t* d_labels, void* strea
         // empty slice: valid (all-pad) lists so that export / assemble need no special case
         if ((rc = e->blk_raw.ensure(((size_t)e->nb + 2) * 4))) return rc;
         KSP_HIP(hipMemsetAsync(e->blk_raw.p, 0, ((size_t)e->nb + 2) * 4, st));
-        hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, e->blk_raw.as<u32>(), e->blk_pos.as<u32>(),
+        hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(1024), 0, st, e->blk_raw.as<u32>(), e->blk_pos.as<u32>(),
                            e->scalars.as<u64>(), e->nb);
         const u64 lpad = (u64)e->nb * (WIN + 4) + 4 * WIN;
         hipLaunchKernelGGL(k_fill, dim3(grid_for(lpad, 256)), dim3(256), 0, st, e->bkeys.as<u32>(), PAD, lpad);
@@ -1959,7 +1973,7 @@ int ksp_engine_assemble(ksp_engine* e, uint32_t nparts, const uint64_t* h_sizes 
     KSP_HIP(hipMemcpyAsync(e->asm_small.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, st));
     u64* scal = e->scalars.as<u64>();
     hipLaunchKernelGGL(k_asm_counts, dim3(1), dim3(64), 0, st, d_blk_raw_all, nb + 1, nparts, nb, e->blk_raw.as<u32>());
-    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(64), 0, st, e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), scal, nb);
+    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(1024), 0, st, e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), scal, nb);
     hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, e->blk_raw.as<u32>(), e->blk_pos.as<u32>(), e->bkeys.as<u32>(), nb, PAD);
     const u32* roff = e->asm_small.as<u32>();
     if (e->weighted)

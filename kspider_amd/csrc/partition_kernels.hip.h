@@ -151,7 +151,11 @@ __global__ void k_part_src(const u64* __restrict__ off, const u32 n_sources, con
     tbl[c] = c < nchunks ? part_source_of(off, n_sources, (u64)c * P1_CH) : n_sources - 1;
 }
 
-template <class V>
+// SORTED: the chunk is put in level-1 bucket order in LDS before it is written, so that the ~16 entries a chunk sends to a
+// bucket leave as ONE run from neighbouring lanes.  For inputs whose sources are so short that consecutive entries almost
+// never share a bucket (1 M read groups of <= 256 hashes over 256 buckets: runs of one entry): written where they stand,
+// every store instruction of a wave scattered 64 single entries over 64 pages — 5.8 GB written for 1.8 GB of entries.
+template <class V, bool SORTED = false>
 __global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ keys, const u64* __restrict__ off,
                                                       const u32 n_sources, const u32 n, u64* __restrict__ scal,
                                                       const int sh1, const int pb2, const u32 nbm1, const PartLists pl,
@@ -232,6 +236,48 @@ __global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ ke
         s_base[tid] = v; s_pg0[tid] = g0; s_pg1[tid] = g1;
     }
     __syncthreads();
+    if (SORTED) {
+        __shared__ u64 s_key[SORTED ? P1_CH : 1];
+        __shared__ V s_tg[SORTED ? P1_CH : 1];
+        __shared__ u8 s_dg[SORTED ? P1_CH : 1], s_bn[SORTED ? P1_CH : 1];
+        __shared__ u32 s_ls[SORTED ? 256 : 1];
+        if (wv == 0) {   // where every bucket's run starts inside the chunk
+            u32 c[4], t = 0;
+#pragma unroll
+            for (u32 i = 0; i < 4; ++i) { c[i] = s_hist[4 * lane + i]; t += c[i]; }
+            u32 inc = t;
+            for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+            u32 run = inc - t;
+#pragma unroll
+            for (u32 i = 0; i < 4; ++i) { s_ls[4 * lane + i] = run; run += c[i]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 j = 0; j < P1_EPT; ++j) {
+            const u32 idx = j * P1_THREADS + tid;
+            if (idx >= cn) continue;
+            const u32 d1 = info[j] & 0xFFu, slot = s_ls[d1] + (info[j] >> 16);
+            const u32 src = s_lo == s_hi ? s_lo : s_src[idx];
+            s_key[slot] = key[j];
+            s_tg[slot] = make_tag<V>(((src / TB) << 8) | (src % TB), 0u);
+            s_dg[slot] = (u8)(info[j] >> 8);
+            s_bn[slot] = (u8)d1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 j = 0; j < P1_EPT; ++j) {
+            const u32 i = j * P1_THREADS + tid;
+            if (i >= cn) continue;
+            const u32 d1 = s_bn[i], base = s_base[d1], v = base + (i - s_ls[d1]);
+            const u32 ph = (v >> P1_PLOG) == (base >> P1_PLOG) ? s_pg0[d1] : s_pg1[d1];
+            if (ph == ~0u) continue;   // (overflow: the build is repeated with the library partition)
+            const size_t a = ((size_t)ph << P1_PLOG) | (v & (P1_PAGE - 1));
+            Kp[a] = s_key[i];
+            Tp[a] = s_tg[i];
+            Dp[a] = s_dg[i];
+        }
+        return;
+    }
 #pragma unroll
     for (u32 j = 0; j < P1_EPT; ++j) {
         const u32 idx = j * P1_THREADS + tid;

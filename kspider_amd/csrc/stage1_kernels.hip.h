@@ -1451,17 +1451,30 @@ __global__ void k_blk_raw(const V* __restrict__ vals, const u32* __restrict__ es
 // Padded layout of the block lists: every list starts at a multiple of 4 entries and is
 // followed by >= WIN pad entries (rank PAD = +inf), so that any 16-byte-aligned window of
 // WIN entries that starts inside a list is sorted and never runs into the next list.
+// padded start of every block list: list b takes its words rounded up to 4, + one window of pads — a prefix sum (every start
+// is a multiple of 4).  One workgroup of 1 024 threads (launched as <<<1, 64>>> by older call sites: any block size works),
+// every thread a contiguous run of blocks; one thread walking all blocks took 0.3 ms for the 7 813 blocks of 1 M sources.
 __global__ void k_blk_pos(const u32* __restrict__ blk_raw, u32* __restrict__ blk_pos, u64* __restrict__ scal, u32 nb) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        u32 pos = 0;
-        for (u32 b = 0; b < nb; ++b) {
-            blk_pos[b] = pos;
-            u32 cnt = blk_raw[b + 1] - blk_raw[b];
-            pos = ((pos + cnt + 3u) & ~3u) + WIN;
-        }
-        blk_pos[nb] = pos;
-        scal[3] = pos;
+    __shared__ u32 s_part[1024];
+    if (blockIdx.x != 0) return;
+    const u32 nt = blockDim.x, tid = threadIdx.x;
+    const u32 per = (nb + nt - 1) / nt, b0 = min(nb, tid * per), b1 = min(nb, b0 + per);
+    u32 sum = 0;
+    for (u32 b = b0; b < b1; ++b) sum += ((blk_raw[b + 1] - blk_raw[b] + 3u) & ~3u) + WIN;
+    s_part[tid] = sum;
+    __syncthreads();
+    for (u32 o = 1; o < nt; o <<= 1) {   // inclusive scan of the per-thread sums
+        const u32 v = tid >= o ? s_part[tid - o] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
     }
+    u32 pos = s_part[tid] - sum;
+    for (u32 b = b0; b < b1; ++b) {
+        blk_pos[b] = pos;
+        pos += ((blk_raw[b + 1] - blk_raw[b] + 3u) & ~3u) + WIN;
+    }
+    if (tid == nt - 1) { blk_pos[nb] = s_part[nt - 1]; scal[3] = s_part[nt - 1]; }
 }
 
 // tail pads of every block list (+inf ranks): from the end of list b to the start of list b + 1, and

@@ -26,7 +26,19 @@ def beat():
 
 
 threading.Thread(target=beat, daemon=True).start()
-sk = synth.generate(cfg)
+# (the generator runs OUTSIDE the profiler: `prof_step.py C4 dump FILE` writes the set, `... load FILE` reads it back —
+#  under rocprofv3 the numpy-heavy generation of C4 took minutes instead of seconds)
+mode = sys.argv[3] if len(sys.argv) > 3 else ""
+path = sys.argv[4] if len(sys.argv) > 4 else ""
+if mode == "load":
+    z = np.load(path)
+    sk = synth.SketchSet(z["keys"], z["offsets"], z["cluster"], cfg)
+else:
+    sk = synth.generate(cfg)
+    if mode == "dump":
+        np.savez(path, keys=sk.keys, offsets=sk.offsets, cluster=sk.cluster)
+        print(f"[prof_step {cfg}] dumped to {path}", flush=True)
+        sys.exit(0)
 print(f"[prof_step {cfg}] {sk.n_sources} sources, {int(sk.offsets[-1])} hashes", flush=True)
 dk = engine.DeviceBuffer.from_numpy(sk.keys)
 e = engine.Engine(0)
