@@ -155,9 +155,20 @@ def dropin_end_to_end(oracle, sub, co, src, w, cpu_threads: int) -> dict:
                     phases[name] = float(line.split(":")[1].split()[0])
             if "device round trip" in line:
                 phases["device_round_trip_s"] = float(line.split("device round trip")[1].split()[0])
-        t = time.perf_counter()
-        secs, n_rows, _ = oracle.ref_pairwise(prefix, cpu_threads)
-        cpu_wall = time.perf_counter() - t
+        # (the restated reference prints its phase line on stdout, as the reference does: kept off this program's stdout,
+        #  which carries the one JSON line)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(devnull, 1)
+        try:
+            t = time.perf_counter()
+            secs, n_rows, _ = oracle.ref_pairwise(prefix, cpu_threads)
+            cpu_wall = time.perf_counter() - t
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+            os.close(devnull)
         want = open(prefix + "_kSpider_pairwise.tsv", "rb").read()
         return {"wall_s": wall, **phases, "tsv_bytes": len(got), "host_threads": threads,
                 "index_bytes": sum(os.path.getsize(prefix + f) for f in ("_color_to_sources.bin", "_color_count.bin", "_groupID_to_kmerCount.bin")),

@@ -198,6 +198,7 @@ struct ksp_engine {
     hipEvent_t ev_join_done = nullptr;   // behind the count copy of the last ksp_engine_join_launch
     hipEvent_t ev_rb = nullptr;          // behind a read-back the host waits for while later kernels are already queued
     double kept_frac = 0.7;              // kept / all entries of the previous build (label sampling before the count is known)
+    double piece_ratio = 0;              // ksp_engine_join_to_host: densest found / bound ratio of the engine's previous call (first piece's size)
     ksp::Buf stage[2];                   // ksp_engine_join_to_host: the edges of a piece wait here for their copy
     hipStream_t copy_stream = nullptr;   // ... which runs on this stream, under the join of the next piece
     hipEvent_t ev_copy[2] = {nullptr, nullptr};
@@ -2313,7 +2314,9 @@ int ksp_engine_join_to_host(ksp_engine* e, uint64_t tile_begin, uint64_t tile_en
     float ms = 0;
     u64 tiles = 0, act = 0, pairs = 0, bytes = 0;
     bool overflow = false;
-    double ratio = 0;      // densest found / bound so far (0: nothing joined yet)
+    double ratio = e->piece_ratio;   // densest found / bound so far (0: nothing joined yet on this engine; else what the previous
+                                     // call saw — a caller that joins the same kind of data again starts with pieces of the right size)
+    double seen = 0;
     u64 shrink = 1;        // (a piece that overflowed: the limit divided by this until one fits)
     u64 t = tile_begin;
     for (u32 k = 0; t < tile_end;) {
@@ -2347,7 +2350,7 @@ int ksp_engine_join_to_host(ksp_engine* e, uint64_t tile_begin, uint64_t tile_en
         }
         if (rc) return rc;
         shrink = 1;
-        if (bound) ratio = std::max(ratio, std::min(1.0, (double)cnt / (double)bound));
+        if (bound) { const double r1 = std::min(1.0, (double)cnt / (double)bound); ratio = std::max(ratio, r1); seen = std::max(seen, r1); }
         tiles += e->st.last_tiles; act += e->st.last_active_tiles; pairs += e->st.last_pairs; bytes += e->st.last_stream_bytes;
         if (total + cnt > capacity) overflow = true;
         else if (cnt) {
@@ -2361,6 +2364,7 @@ int ksp_engine_join_to_host(ksp_engine* e, uint64_t tile_begin, uint64_t tile_en
         ++k;
     }
     KSP_HIP(hipStreamSynchronize(e->copy_stream));
+    e->piece_ratio = seen;
     *h_count = total;
     e->st.ms_join = ms; e->st.last_tiles = tiles; e->st.last_active_tiles = act; e->st.last_pairs = pairs; e->st.last_stream_bytes = bytes;
     e->st.last_edges = total;
