@@ -201,6 +201,8 @@ struct ksp_engine {
     double piece_ratio = 0;              // ksp_engine_join_to_host: densest found / bound ratio of the engine's previous call (first piece's size)
     ksp::Buf stage[2];                   // ksp_engine_join_to_host: the edges of a piece wait here for their copy
     hipStream_t copy_stream = nullptr;   // ... which runs on this stream, under the join of the next piece
+    hipStream_t aux_stream = nullptr;    // the 32-bit-counter pass of a join runs here, beside the 16-bit pass
+    hipEvent_t ev_aux[2] = {nullptr, nullptr};
     hipEvent_t ev_copy[2] = {nullptr, nullptr};
     bool join_pending = false;           // a launched join whose count has not been collected (ksp_engine_join_wait)
     u64 join_cap = 0;
@@ -1375,6 +1377,8 @@ void ksp_engine_destroy(ksp_engine* e) {
                         &e->mr0, &e->mr1, &e->mstart, &e->stage[0], &e->stage[1]};
     for (auto* b : bufs) b->release();
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    if (e->aux_stream) (void)hipStreamDestroy(e->aux_stream);
+    for (int i = 0; i < 2; ++i) if (e->ev_aux[i]) (void)hipEventDestroy(e->ev_aux[i]);
     for (int i = 0; i < 2; ++i) if (e->ev_copy[i]) (void)hipEventDestroy(e->ev_copy[i]);
     if (e->h_count) (void)hipHostFree(e->h_count);
     if (e->h_scal) (void)hipHostFree(e->h_scal);
@@ -2163,11 +2167,39 @@ int ksp_engine_join_launch(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end
             a.wgt = wgt_buf.as<unsigned long long>();
         }
 #endif
-        for (int pass = 0; pass < (e->need32 ? 2 : 1); ++pass)
+        // Two passes over the work list when some tile pairs two blocks that both hold a source of >= 2^16 k-mers: the
+        // tiles with packed 16-bit counters, then those with 32-bit counters (64 KB of LDS: two workgroups per CU).  The
+        // second pass runs on a stream of its own BESIDE the first — its few fat workgroups leave most of every CU's
+        // wave slots free (metagenome bins: 9.2 + 4.3 ms one after the other).
+        bool two_streams = e->need32 && !std::getenv("KSP_DEBUG_ONE_STREAM");
+        if (two_streams) {
+            if (!e->aux_stream && hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) != hipSuccess) two_streams = false;
+            for (int i = 0; i < 2 && two_streams; ++i)
+                if (!e->ev_aux[i] && hipEventCreateWithFlags(&e->ev_aux[i], hipEventDisableTiming) != hipSuccess) two_streams = false;
+        }
+        if (two_streams) {
+            KSP_HIP(hipEventRecord(e->ev_aux[0], st));                    // (the zeroing launch above)
+            KSP_HIP(hipStreamWaitEvent(e->aux_stream, e->ev_aux[0], 0));
+        }
+        for (int pass = 0; pass < (e->need32 ? 2 : 1); ++pass) {
+            hipStream_t ps = (pass == 1 && two_streams) ? e->aux_stream : st;
             for (u64 w = wgA; w < wgB; w += kMaxTilesPerLaunch) {
                 a.wg0 = (u32)w;
-                launch(pass == 0, dim3((u32)std::min<u64>(kMaxTilesPerLaunch, wgB - w)), a);
+                const dim3 grid((u32)std::min<u64>(kMaxTilesPerLaunch, wgB - w));
+                const bool c16 = pass == 0;
+                if (e->use_cells) {
+                    if (e->weighted) { if (c16) hipLaunchKernelGGL((k_join<true, true, true>), grid, block, 0, ps, a); else hipLaunchKernelGGL((k_join<true, false, true>), grid, block, 0, ps, a); }
+                    else { if (c16) hipLaunchKernelGGL((k_join<false, true, true>), grid, block, 0, ps, a); else hipLaunchKernelGGL((k_join<false, false, true>), grid, block, 0, ps, a); }
+                } else {
+                    if (e->weighted) { if (c16) hipLaunchKernelGGL((k_join<true, true, false>), grid, block, 0, ps, a); else hipLaunchKernelGGL((k_join<true, false, false>), grid, block, 0, ps, a); }
+                    else { if (c16) hipLaunchKernelGGL((k_join<false, true, false>), grid, block, 0, ps, a); else hipLaunchKernelGGL((k_join<false, false, false>), grid, block, 0, ps, a); }
+                }
             }
+        }
+        if (two_streams) {
+            KSP_HIP(hipEventRecord(e->ev_aux[1], e->aux_stream));
+            KSP_HIP(hipStreamWaitEvent(st, e->ev_aux[1], 0));             // (the count is read behind both passes)
+        }
         KSP_HIP(hipGetLastError());
     }
     if (zj.n) { hipLaunchKernelGGL(k_zero_regions, dim3(1), dim3(64), 0, st, zj); zj.n = 0; }   // (dense mode: the edge counter)

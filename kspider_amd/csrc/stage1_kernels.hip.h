@@ -849,6 +849,8 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
     if (E1 < m) { r_hi = rank[blockIdx.x + 1]; if (first[r_hi] != E1) ++r_hi; }
     if (r_lo >= r_hi) return;
     const u32 Eend = min(first[r_hi], E0 + KG_CHUNK + KG_MAXC);
+    // (all of a thread's tag loads and look-ups issued together instead of this loop — the round-3 cure for k_fkeys — made
+    //  this kernel SLOWER: C2 build 1.13 -> 1.18 ms, 100 000 genomes 18.4 -> 19.9; six workgroups per CU hide the loop's waits)
     for (u32 i = threadIdx.x; E0 + i < Eend; i += KG_THREADS) s_idx[i] = newidx[src_of_tag(tag_of(vals[E0 + i]))];
     __syncthreads();
     __shared__ u32 s_big[(KG_CHUNK + KG_MAXC) / KG_COOP_MIN + 8], s_nbig;
