@@ -2866,6 +2866,12 @@ int ksp_debug_fktime(unsigned long long* out16, int reset) {
     if (reset) { unsigned long long z[16] = {0}; KSP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ksp::fk_time), z, 16 * 8)); }
     return KSP_OK;
 }
+int ksp_debug_sttime(unsigned long long* out64, int reset) {
+    KSP_HIP(hipDeviceSynchronize());
+    KSP_HIP(hipMemcpyFromSymbol(out64, HIP_SYMBOL(ksp::st_time), 64 * 8));
+    if (reset) { unsigned long long z[64] = {0}; KSP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ksp::st_time), z, 64 * 8)); }
+    return KSP_OK;
+}
 #endif
 
 }  // extern "C"

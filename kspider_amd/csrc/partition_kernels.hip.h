@@ -678,6 +678,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
     __shared__ u32 s_w[P2_THREADS / 64];
     u32* const ovf = reinterpret_cast<u32*>(scal + PC_OVF);
     if (part_ovf_uniform(ovf)) return;
+    ST_BEGIN();
     const u32 g = blockIdx.x / nb1, B = blockIdx.x % nb1;   // (consecutive workgroups read neighbouring segments of the same sources)
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 s0 = groups[g], ns = groups[g + 1] - s0;        // (<= SEG_SMAX by construction)
@@ -694,6 +695,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
     if (lane == 63) s_w[wv] = inc;
     if (tid < 256) s_cnt[tid] = 0;
     __syncthreads();
+    ST_T(48);
     u32 run = inc - len, m = 0;
     for (u32 w = 0; w < P2_THREADS / 64; ++w) { if (w < wv) run += s_w[w]; m += s_w[w]; }
     if (tid < ns) s_pre[tid] = run;
@@ -703,6 +705,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
         return;
     }
     __syncthreads();
+    ST_T(49);
     // gather straight into registers: entry i of the tile lies in the segment sg with s_pre[sg] <= i < s_pre[sg + 1]
     // (bisection in LDS; neighbouring threads read neighbouring entries of the same segment).  All loads of a thread
     // are in flight together: a loop over the segments would be one memory round trip per segment.
@@ -733,7 +736,8 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
         rk[k] = part_bucket(key[k], mult, ident, nbm1) & nb2m1;
         if (i < m) rk[k] |= atomicAdd(&s_cnt[rk[k]], 1u) << 8;
     }
-    __syncthreads();   // (also: every thread holds its entries in registers, the staging buffers are free)
+    __syncthreads();
+    ST_T(50);   // (also: every thread holds its entries in registers, the staging buffers are free)
     if (wv == 0) {   // where every bucket's run starts inside the tile
         u32 c[4], t = 0;
 #pragma unroll
@@ -753,6 +757,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
         }
     }
     __syncthreads();
+    ST_T(51);
 #pragma unroll
     for (u32 k = 0; k < P2_EPT; ++k) {
         const u32 i = k * P2_THREADS + tid;
@@ -764,6 +769,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
         }
     }
     __syncthreads();
+    ST_T(52);
 #pragma unroll
     for (u32 k = 0; k < P2_EPT; ++k) {
         const u32 i = k * P2_THREADS + tid;
@@ -773,6 +779,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
             T2[dst] = s_tag[i];
         }
     }
+    ST_T(56);
 }
 
 // Sets of more than 65 536 buckets (three levels): the same trick for THEIR level 1 — one workgroup per (group of

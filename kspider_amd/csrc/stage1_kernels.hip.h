@@ -19,6 +19,16 @@ static_assert(TB == 128, "compact tags: 7-bit local ids");
 // ------------------------------------------------------------------------------------
 // stage 1 kernels
 // ------------------------------------------------------------------------------------
+// (timing build, make fktime: thread 0 of every workgroup adds the shader-clock time since its previous mark to
+//  st_time[slot]; tools/fk_times.py prints the shares.  Slots: 16.. k_key_groups, 32.. k_bucket_group, 48.. k_seg_scatter)
+#ifdef KSP_FKTIME
+__device__ unsigned long long st_time[64];
+#define ST_BEGIN() unsigned long long st_last_ = clock64()
+#define ST_T(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); atomicAdd(&st_time[k], now_ - st_last_); st_last_ = now_; } } while (0)
+#else
+#define ST_BEGIN() do { } while (0)
+#define ST_T(k) do { } while (0)
+#endif
 
 // One workgroup per source: tag each entry with (block << 8 | local id) [and weight].
 // Weighted mode also records the source's weight sum (the bound of any pair counter that source
@@ -486,26 +496,39 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
     constexpr u32 PER = (HB_SLOTS + 1 + NT - 1) / NT;
     const u32 tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
+    // bounds two buckets ahead (round 3): the words of bucket b + 2 x grid are loaded at the head of pass b through a
+    // lane-private zero — the compiler cannot tell that the address is uniform, so they stay in vector registers, nobody
+    // waits for them — and first looked at when the pass ends.  Before, the next bucket's bounds were two or three scalar
+    // loads at the head of every pass, each waited for on the spot (s_waitcnt lgkmcnt(0)): memory round trips in front of
+    // the table initialisation, in the stage that was half of every pass (tools/st_times.py).
+    u32 vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     u32 b = blockIdx.x;
-    u32 b0 = 0, raw = 0;
+    u32 b0 = 0, raw = 0, n0 = 0, nraw = 0;
     if (b < nbuckets) { b0 = bb.first(b); raw = bb.size(b); }
+    if (b + gridDim.x < nbuckets) { n0 = bb.first(b + gridDim.x); nraw = bb.size(b + gridDim.x); }
     u32 size = raw > HB_CAP ? 0 : raw;   // a bucket that does not fit is skipped here: k_bucket_big takes it
     unsigned long long mykey[EPT], nkey[EPT];
 #pragma unroll
     for (u32 j = 0; j < EPT; ++j) mykey[j] = tid + j * NT < size ? keys[b0 + tid + j * NT] : 0;
+    ST_BEGIN();
     while (b < nbuckets) {
         if (raw > HB_CAP && tid == 0) {   // left to k_bucket_big (overflow[1] counts them)
             const u32 q = atomicAdd(&overflow[1], 1u);
             big_list[q] = b;   // (one slot per bucket: cannot overflow)
         }
-        const u32 bn = b + gridDim.x;
-        u32 n0 = 0, nraw = 0;           // bounds of the next bucket
-        if (bn < nbuckets) { n0 = bb.first(bn); nraw = bb.size(bn); }
+        const u32 bn = b + gridDim.x, bnn = bn + gridDim.x;
+        u32 la = 0, lb = 0;   // (the words as loaded; first / size are worked out when the pass ends)
+        if (bnn < nbuckets) {
+            if (bb.cap) la = bb.cnt[bnn + vzero];
+            else { la = bb.start[bnn + vzero]; lb = bb.start[bnn + 1 + vzero]; }
+        }
         // the table is as large as the bucket needs (load at most 13/16 even if no two keys are equal)
         const u32 slots = size <= 416 ? 512u : size <= 832 ? 1024u : size <= 1664 ? 2048u : HB_SLOTS;
         for (u32 i = tid; i <= slots; i += NT) tkey[i] = EMPTY;
         for (u32 i = tid; i <= slots / 2; i += NT) tcnt2[i] = 0;
         __syncthreads();
+        ST_T(32);
 #pragma unroll
         for (u32 j = 0; j < EPT; ++j) {
             const u32 i = tid + j * NT;
@@ -530,6 +553,7 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
 #pragma unroll
         for (u32 j = 0; j < EPT; ++j) nkey[j] = tid + j * NT < nsize ? keys[n0 + tid + j * NT] : 0;
         __syncthreads();
+        ST_T(33);
         // exclusive scan over the slots of (kept entries | kept keys << 16): up to 9 slots per thread
         const u32 per = slots / NT + 1;
         u32 cnt[PER];
@@ -544,6 +568,7 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
         for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if (lane >= o) inc += up; }
         if (lane == 63) wpart[wv] = inc;
         __syncthreads();
+        ST_T(34);
         u32 run = inc - mine;
         for (int w = 0; w < wv; ++w) run += wpart[w];
         if (tid == NT - 1) {   // the last thread's inclusive sum: the bucket's total
@@ -557,6 +582,7 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
             if (cnt[j] >= 2) run += cnt[j] | (1u << 16);
         }
         __syncthreads();
+        ST_T(35);
 #pragma unroll
         for (u32 j = 0; j < EPT; ++j) {
             const u32 i = tid + j * NT;
@@ -571,9 +597,15 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
             rec[b0 + i] = (unsigned short)r;
         }
         b = bn; b0 = n0; raw = nraw; size = nsize;
+        {
+            const u32 ua = __builtin_amdgcn_readfirstlane(la), ub = __builtin_amdgcn_readfirstlane(lb);
+            n0 = bnn < nbuckets ? (bb.cap ? bnn * bb.cap : ua) : 0u;
+            nraw = bnn < nbuckets ? (bb.cap ? min(ua, bb.cap) : ub - ua) : 0u;
+        }
 #pragma unroll
         for (u32 j = 0; j < EPT; ++j) mykey[j] = nkey[j];
-        __syncthreads();   // the table is rebuilt from here on
+        __syncthreads();
+        ST_T(36);   // the table is rebuilt from here on
     }
 }
 
@@ -840,6 +872,7 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
                                                            u32* __restrict__ wkey, u32* __restrict__ ovf, const u32 coop,
                                                            u32* __restrict__ huge_list) {
     __shared__ u32 s_idx[KG_CHUNK + KG_MAXC + 4];
+    ST_BEGIN();
     const u32 E0 = blockIdx.x * KG_CHUNK, E1 = min(m, E0 + KG_CHUNK);
     // the keys that start inside [E0, E1)
     static_assert(KG_CHUNK == CR_CHUNK, "crank[] holds the rank of every KG_CHUNK-th entry");
@@ -849,10 +882,12 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
     if (E1 < m) { r_hi = rank[blockIdx.x + 1]; if (first[r_hi] != E1) ++r_hi; }
     if (r_lo >= r_hi) return;
     const u32 Eend = min(first[r_hi], E0 + KG_CHUNK + KG_MAXC);
+    ST_T(16);
     // (all of a thread's tag loads and look-ups issued together instead of this loop — the round-3 cure for k_fkeys — made
     //  this kernel SLOWER: C2 build 1.13 -> 1.18 ms, 100 000 genomes 18.4 -> 19.9; six workgroups per CU hide the loop's waits)
     for (u32 i = threadIdx.x; E0 + i < Eend; i += KG_THREADS) s_idx[i] = newidx[src_of_tag(tag_of(vals[E0 + i]))];
     __syncthreads();
+    ST_T(17);
     __shared__ u32 s_big[(KG_CHUNK + KG_MAXC) / KG_COOP_MIN + 8], s_nbig;
     if (threadIdx.x == 0) s_nbig = 0;
     // one group of key r: block `cur`, members lo | hi.  The key's first group goes to the per-key arrays, the
@@ -922,7 +957,9 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
         }
         gsum[r] = (u64)groups | ((u64)bigs << 32);
     }
+    ST_T(18);
     __syncthreads();
+    ST_T(19);
     // keys with many holders, one wave each.  Round 3: two strided passes over the holders whatever the number of blocks —
     // the smallest block (wave minimum), then every holder ORs its bit into a table of 32 blocks x 128 bits in LDS (related
     // sources are neighbours after the reordering: a key's blocks are a short range); the 32 table rows are then read by 32
@@ -1005,6 +1042,7 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
         }
         if (lane == 0) gsum[r] = (u64)groups | ((u64)bigs << 32);
     }
+    ST_T(20);
 }
 // crank[] from a per-entry rank array (the sort path and the postings input produce one) / the per-entry array from
 // first[] (the sort-by-block fallback after a grouping that only wrote crank[])
