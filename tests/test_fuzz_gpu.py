@@ -11,7 +11,13 @@ pytestmark = pytest.mark.gpu
 MODES = [{}, {"KSP_REORDER": "0"}, {"KSP_NO_SCHED": "1"}, {"KSP_COLLECT": "1"}, {"KSP_COLLECT": "0"},
          {"KSP_JOIN": "window"}, {"KSP_TAG32": "1"}, {"KSP_HASH_GROUP": "0"}, {"KSP_KEY_GROUPS": "0"},
          {"KSP_KEY_GROUPS": "0", "KSP_REORDER": "0"}, {"KSP_PART_MIN": "1"}, {"KSP_PARTITION": "rocprim"}, {"KSP_JOIN": "matches"}, {"KSP_JOIN": "matches", "KSP_COLLECT": "0"},
-         {"KSP_JOIN": "matches", "KSP_COLLECT": "1", "KSP_REORDER": "0"}, {"KSP_ALIGN": "0"}, {"KSP_ALIGN": "0", "KSP_KEY_GROUPS": "0"}, {"KSP_PART_MIN": "1", "KSP_SEG": "1"}, {"KSP_PART_MIN": "1", "KSP_SEG": "0"}, {"KSP_MS": "0"}, {"KSP_MS": "0", "KSP_REORDER": "0"}]
+         {"KSP_JOIN": "matches", "KSP_COLLECT": "1", "KSP_REORDER": "0"}, {"KSP_ALIGN": "0"}, {"KSP_ALIGN": "0", "KSP_KEY_GROUPS": "0"}, {"KSP_PART_MIN": "1", "KSP_SEG": "1"}, {"KSP_PART_MIN": "1", "KSP_SEG": "0"}, {"KSP_MS": "0"}, {"KSP_MS": "0", "KSP_REORDER": "0"},
+         # the bucket-resident middle of stage 1 (fused_kernels.hip.h): tiny inputs too (KSP_PART_MIN=1), paged and segment partition,
+         # 32-bit tags, plain block cuts, one bucket per chunk of k_fkeys and many, sorted level 1 of the paged partition
+         {"KSP_FUSED": "1", "KSP_PART_MIN": "1"}, {"KSP_FUSED": "1", "KSP_PART_MIN": "1", "KSP_SEG": "1"},
+         {"KSP_FUSED": "1", "KSP_PART_MIN": "1", "KSP_SEG": "0", "KSP_TAG32": "1"}, {"KSP_FUSED": "1", "KSP_PART_MIN": "1", "KSP_ALIGN": "0"},
+         {"KSP_FUSED": "1", "KSP_PART_MIN": "1", "KSP_DEBUG_FK_GB": "1"}, {"KSP_FUSED": "1", "KSP_PART_MIN": "1", "KSP_DEBUG_FK_GB": "32", "KSP_COLLECT": "0"},
+         {"KSP_PART_MIN": "1", "KSP_SEG": "0", "KSP_DEBUG_PART_SORTED": "1"}, {"KSP_DEBUG_LABEL_SPREAD": "0"}]
 
 
 def _random_sketches(rng):
@@ -39,7 +45,8 @@ def test_random_sketches_all_modes(oracle_lib, seed, monkeypatch):
         ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
         for env in MODES:
             for k in ("KSP_REORDER", "KSP_NO_SCHED", "KSP_COLLECT", "KSP_JOIN", "KSP_TAG32", "KSP_HASH_GROUP", "KSP_KEY_GROUPS",
-                      "KSP_PART_MIN", "KSP_PARTITION", "KSP_ALIGN", "KSP_SEG", "KSP_MS"):
+                      "KSP_PART_MIN", "KSP_PARTITION", "KSP_ALIGN", "KSP_SEG", "KSP_MS", "KSP_FUSED", "KSP_DEBUG_FK_GB",
+                      "KSP_DEBUG_PART_SORTED", "KSP_DEBUG_LABEL_SPREAD"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
