@@ -150,3 +150,39 @@ def test_join_to_host_in_pieces_equals_one_join(monkeypatch):
         eng.join_to_host(0, T, host.ctypes.data, max(1, n // 2))
     assert ei.value.code == engine.KSP_E_OVERFLOW and ei.value.count == n
     eng.close()
+
+
+def test_pipelined_join_reports_overflow_at_the_wait_and_step_launch_collects_it():
+    """ksp_engine_join_launch into a buffer that is too small, the next build queued behind it, ksp_engine_join_wait: the
+    overflow is only known at the wait (include/kspider_amd.h: size the buffer from ksp_engine_edge_bound first) and carries
+    the full count.  ksp_engine_step_launch does build + range + bound + launch in one call, refuses to launch into a
+    buffer below the bound, and hands back the count of the join that was pending."""
+    sk = synth.generate("C2", n_sources=2000, seed=78)
+    keys_d = engine.DeviceBuffer.from_numpy(sk.keys)
+    eng = engine.Engine(0)
+    eng.build_blocks(keys_d.ptr.value, sk.offsets)
+    T = eng.num_tiles
+    cap = int(eng.edge_bound(0, T)) + 1
+    ed = engine.DeviceBuffer(cap * 16)
+    n = eng.join(0, T, ed.ptr.value, cap)
+    assert n > 1000
+    eng.join_launch(0, T, ed.ptr.value, n // 3)          # too small: the surplus is dropped, the count keeps running
+    eng.build_blocks(keys_d.ptr.value, sk.offsets)       # (the next step's stage 1 runs behind the join)
+    with pytest.raises(engine.KspError) as ei:
+        eng.join_wait()
+    assert ei.value.code == engine.KSP_E_OVERFLOW and str(n) in str(ei.value)
+    # step_launch: no launch below the bound; then a launch, and the next call collects its count
+    t0, t1, bound, launched, prev = eng.step_launch(keys_d.ptr.value, sk.offsets, 0, 1, ed.ptr.value, 10)
+    assert (t0, t1) == (0, T) and bound + 1 > 10 and not launched and prev is None
+    t0, t1, bound, launched, prev = eng.step_launch(keys_d.ptr.value, sk.offsets, 0, 1, ed.ptr.value, cap)
+    assert launched and prev is None and bound < cap
+    t0, t1, bound, launched, prev = eng.step_launch(keys_d.ptr.value, sk.offsets, 0, 1, ed.ptr.value, cap)
+    assert launched and prev == n
+    assert eng.join_wait() == n
+    # two ranks' ranges partition the tiles
+    a = eng.step_launch(keys_d.ptr.value, sk.offsets, 0, 2, ed.ptr.value, cap)
+    n0 = eng.join_wait()
+    b = eng.step_launch(keys_d.ptr.value, sk.offsets, 1, 2, ed.ptr.value, cap)
+    n1 = eng.join_wait()
+    assert a[0] == 0 and a[1] == b[0] and b[1] == T and n0 + n1 == n
+    eng.close()
