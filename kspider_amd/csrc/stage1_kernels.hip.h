@@ -888,7 +888,12 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
     for (u32 i = threadIdx.x; E0 + i < Eend; i += KG_THREADS) s_idx[i] = newidx[src_of_tag(tag_of(vals[E0 + i]))];
     __syncthreads();
     ST_T(17);
-    __shared__ u32 s_big[(KG_CHUNK + KG_MAXC) / KG_COOP_MIN + 8], s_nbig;
+    // keys left to a whole wave (below): rank - r_lo, and (filled by the thread that lists the key, which has both words in
+    // registers) where its entries start in the staging and how many there are — the wave-per-key pass then needs no memory
+    // load per key (first[r], first[r + 1] were a round trip at the head of every key, behind the previous key's stores)
+    constexpr u32 KG_NBIG = (KG_CHUNK + KG_MAXC) / KG_COOP_MIN + 8;
+    __shared__ unsigned short s_big[KG_NBIG], s_bigf[KG_NBIG], s_bigc[KG_NBIG];
+    __shared__ u32 s_nbig;
     if (threadIdx.x == 0) s_nbig = 0;
     // one group of key r: block `cur`, members lo | hi.  The key's first group goes to the per-key arrays, the
     // others are parked at the key's entry positions (every lane of a cooperating wave counts, one stores).
@@ -926,7 +931,10 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
             continue;
         }
         if (c > coop) {   // many holders: a whole wave walks this key (below)
-            s_big[atomicAdd(&s_nbig, 1u)] = r;
+            const u32 slot = atomicAdd(&s_nbig, 1u);
+            s_big[slot] = (unsigned short)(r - r_lo);
+            s_bigf[slot] = (unsigned short)f0;
+            s_bigc[slot] = (unsigned short)c;
             continue;
         }
         if (W && c) wkey[r] = weight_of(vals[fa]);
@@ -970,8 +978,8 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
     __shared__ u32 s_wtab[KG_THREADS / 64][32 * 4];
     u32* const tab = s_wtab[wv];
     for (u32 q = wv; q < s_nbig; q += KG_THREADS / 64) {
-        const u32 r = s_big[q];
-        const u32 fa = first[r], c = first[r + 1] - fa, f0 = fa - E0;
+        const u32 r = r_lo + s_big[q];
+        const u32 f0 = s_bigf[q], c = s_bigc[q], fa = E0 + f0;
         if (W && lane == 0) wkey[r] = weight_of(vals[fa]);
         u32 bmin = ~0u, bmax = 0;
         for (u32 i = lane; i < c; i += 64) { const u32 b = s_idx[f0 + i] / TB; bmin = min(bmin, b); bmax = max(bmax, b); }

@@ -44,6 +44,7 @@ dk = engine.DeviceBuffer.from_numpy(sk.keys)
 e = engine.Engine(0)
 de = None
 out = {}
+builds, joins = [], []
 for s in range(steps):
     e.build_blocks(dk.ptr.value, sk.offsets)
     T = e.num_tiles
@@ -52,7 +53,9 @@ for s in range(steps):
         de = engine.DeviceBuffer(cap * 16)
     n = e.join(0, T, de.ptr.value, cap)
     st = e.stats()
-    out = {"config": cfg, "step": s, "build_ms": st["ms_build"], "join_ms": st["ms_join"], "edges": int(n),
+    builds.append(st["ms_build"]); joins.append(st["ms_join"])
+    out = {"config": cfg, "step": s, "build_ms": st["ms_build"], "join_ms": st["ms_join"],
+           "build_ms_min": min(builds[1:] or builds), "join_ms_min": min(joins[1:] or joins), "edges": int(n),
            "partition_kind": st["partition_kind"], "stage1_kind": st["stage1_kind"], "kept_entries": int(st["n_kept_entries"]),
            "kept_keys": int(st["n_kept_keys"]), "list_words": int(st["n_block_keys"]), "active_tiles": int(st["n_active_tiles"])}
     print(json.dumps(out), flush=True)
