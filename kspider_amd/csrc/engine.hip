@@ -2869,7 +2869,7 @@ int ksp_debug_fktime(unsigned long long* out16, int reset) {
 int ksp_debug_sttime(unsigned long long* out64, int reset) {
     KSP_HIP(hipDeviceSynchronize());
     KSP_HIP(hipMemcpyFromSymbol(out64, HIP_SYMBOL(ksp::st_time), 64 * 8));
-    if (reset) { unsigned long long z[64] = {0}; KSP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ksp::st_time), z, 64 * 8)); }
+    if (reset) { unsigned long long z[64] = {0}; z[63] = reset == 2; KSP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ksp::st_time), z, 64 * 8)); }   // (2: probe waits on)
     return KSP_OK;
 }
 #endif

@@ -662,6 +662,38 @@ __global__ __launch_bounds__(64 * SEG_BW) void k_seg_bounds(const u64* __restric
         for (u32 j = 1 + lane; j <= nb1; j += 64) row[j] = 0;
 }
 
+// Tile (group of sources g, range B) of a workgroup of k_seg_scatter / k_seg_mid (grid = groups x nb1).  Workgroups are
+// handed to the eight XCDs (one L2 each) in turn.  An XCD gets a STRIP of ranges, for every group of sources: the tiles
+// (g, B), (g, B + 1) — whose segments meet inside a memory line — follow each other on the same XCD, and so do (g, B),
+// (g + 1, B), whose runs meet inside the lines of the same buckets (partial lines merge in that L2 instead of leaving
+// eight of them one by one).  Bijective for any grid; only the last strip is narrower.
+__device__ inline void seg_tile_of(const u32 nb1, u32& g, u32& B) {
+    const u32 nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7u, x = blockIdx.x & 7u;
+    const u32 vid = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (blockIdx.x >> 3);
+    const u32 ng = nwg / nb1, W = max(1u, nb1 >> 3), t = min(vid / (ng * W), (nb1 - 1) / W);
+    const u32 rem = vid - t * ng * W, wt = min(W, nb1 - t * W);
+    g = rem / wt;
+    B = t * W + rem % wt;
+}
+
+// Segment of every entry of a thread (entry i lies in segment sg with s_pre[sg] <= i < s_pre[sg + 1]; s_pre[ns] = m is
+// above every entry): all of the thread's searches advance in step, so a halving costs ONE round trip to LDS with
+// P2_EPT reads in flight.  (Round 2 bisected entry by entry: loops of data-dependent length the compiler cannot
+// interleave — P2_EPT x log2(ns) dependent LDS reads, ~60 round trips per thread in front of the key loads.)
+template <u32 EPT, u32 NT>
+__device__ inline void seg_of_entries(const u32* s_pre, const u32 ns, const u32 tid, u32 (&sg)[EPT]) {
+#pragma unroll
+    for (u32 k = 0; k < EPT; ++k) sg[k] = 0;
+    u32 st = ns > 1 ? 1u << (31 - __builtin_clz(ns - 1)) : 0u;   // (uniform: the largest power of two below ns)
+    for (; st; st >>= 1) {
+#pragma unroll
+        for (u32 k = 0; k < EPT; ++k) {
+            const u32 c = min(sg[k] + st, ns);
+            if (s_pre[c] <= k * NT + tid) sg[k] = c;
+        }
+    }
+}
+
 // one workgroup per (group of sources, range): gather the tile from the segments, then the counting sort of k_scatter2.
 // gcur[b] (zero at launch) counts the entries of final bucket b, which owns the places [b x cap, (b + 1) x cap).
 template <class V>
@@ -679,7 +711,8 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
     u32* const ovf = reinterpret_cast<u32*>(scal + PC_OVF);
     if (part_ovf_uniform(ovf)) return;
     ST_BEGIN();
-    const u32 g = blockIdx.x / nb1, B = blockIdx.x % nb1;   // (consecutive workgroups read neighbouring segments of the same sources)
+    u32 g, B;
+    seg_tile_of(nb1, g, B);
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 s0 = groups[g], ns = groups[g + 1] - s0;        // (<= SEG_SMAX by construction)
     // the segments: start address and length, exclusive scan of the lengths = start slot inside the tile
@@ -715,27 +748,30 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
     u64 key[P2_EPT];
     V tag[P2_EPT];
     u32 rk[P2_EPT];
+    u32 sg[P2_EPT];
+    seg_of_entries<P2_EPT, P2_THREADS>(s_pre, ns, tid, sg);
+    ST_T(53);
 #pragma unroll
     for (u32 k = 0; k < P2_EPT; ++k) {
         const u32 i = k * P2_THREADS + tid;
         key[k] = 0; tag[k] = V(0);
         if (i < m) {
-            u32 lo = 0, hi = ns;   // s_pre[lo] <= i < s_pre[hi]
-            while (hi - lo > 1) {
-                const u32 mid = (lo + hi) >> 1;
-                if (s_pre[mid] <= i) lo = mid; else hi = mid;
-            }
+            const u32 lo = sg[k];
             key[k] = __builtin_nontemporal_load(keys + s_addr[lo] + (i - s_pre[lo]));
             const u32 src = s0 + lo;
             tag[k] = make_tag<V>(((src / TB) << 8) | (src % TB), 0u);
         }
     }
+#ifdef KSP_FKTIME
+    __builtin_amdgcn_s_waitcnt(0x0F70); ST_T(54);   // (timing build: the key loads alone)
+#endif
 #pragma unroll
     for (u32 k = 0; k < P2_EPT; ++k) {
         const u32 i = k * P2_THREADS + tid;
         rk[k] = part_bucket(key[k], mult, ident, nbm1) & nb2m1;
         if (i < m) rk[k] |= atomicAdd(&s_cnt[rk[k]], 1u) << 8;
     }
+    ST_T(55);
     __syncthreads();
     ST_T(50);   // (also: every thread holds its entries in registers, the staging buffers are free)
     if (wv == 0) {   // where every bucket's run starts inside the tile
@@ -780,6 +816,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
         }
     }
     ST_T(56);
+    ST_END(48);
 }
 
 // Sets of more than 65 536 buckets (three levels): the same trick for THEIR level 1 — one workgroup per (group of
@@ -801,7 +838,8 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_mid(const u64* __restrict__ 
     __shared__ u32 s_w[P2_THREADS / 64];
     u32* const ovf = reinterpret_cast<u32*>(scal + PC_OVF);
     if (part_ovf_uniform(ovf)) return;
-    const u32 g = blockIdx.x / nb1, BA = blockIdx.x % nb1;
+    u32 g, BA;
+    seg_tile_of(nb1, g, BA);
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 s0 = groups[g], ns = groups[g + 1] - s0;        // (<= SEG_SMAX by construction)
     u32 len = 0;
@@ -831,16 +869,14 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_mid(const u64* __restrict__ 
     u64 key[P2_EPT];
     V tag[P2_EPT];
     u32 rk[P2_EPT], dig[P2_EPT];
+    u32 sg[P2_EPT];
+    seg_of_entries<P2_EPT, P2_THREADS>(s_pre, ns, tid, sg);
 #pragma unroll
     for (u32 k = 0; k < P2_EPT; ++k) {
         const u32 i = k * P2_THREADS + tid;
         key[k] = 0; tag[k] = V(0);
         if (i < m) {
-            u32 lo = 0, hi = ns;   // s_pre[lo] <= i < s_pre[hi]
-            while (hi - lo > 1) {
-                const u32 mid = (lo + hi) >> 1;
-                if (s_pre[mid] <= i) lo = mid; else hi = mid;
-            }
+            const u32 lo = sg[k];
             key[k] = __builtin_nontemporal_load(keys + s_addr[lo] + (i - s_pre[lo]));
             const u32 src = s0 + lo;
             tag[k] = make_tag<V>(((src / TB) << 8) | (src % TB), 0u);

@@ -23,11 +23,16 @@ static_assert(TB == 128, "compact tags: 7-bit local ids");
 //  st_time[slot]; tools/fk_times.py prints the shares.  Slots: 16.. k_key_groups, 32.. k_bucket_group, 48.. k_seg_scatter)
 #ifdef KSP_FKTIME
 __device__ unsigned long long st_time[64];
-#define ST_BEGIN() unsigned long long st_last_ = clock64()
-#define ST_T(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); atomicAdd(&st_time[k], now_ - st_last_); st_last_ = now_; } } while (0)
+// (sums in registers, one atomic per stage when the workgroup ends: a global atomic per mark is itself memory traffic
+//  that the kernel's next s_waitcnt vmcnt(0) waits for — timers built that way moved half of k_bucket_group's time into
+//  the stage that held the wait)
+#define ST_BEGIN() unsigned long long st_last_ = clock64(), st_acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define ST_T(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); st_acc_[(k) & 15] += now_ - st_last_; st_last_ = now_; } } while (0)
+#define ST_END(base) do { if (threadIdx.x == 0) { for (int q_ = 0; q_ < 16; ++q_) if (st_acc_[q_]) atomicAdd(&st_time[(base) + q_], st_acc_[q_]); } } while (0)
 #else
 #define ST_BEGIN() do { } while (0)
 #define ST_T(k) do { } while (0)
+#define ST_END(base) do { } while (0)
 #endif
 
 // One workgroup per source: tag each entry with (block << 8 | local id) [and weight].
@@ -512,6 +517,9 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
 #pragma unroll
     for (u32 j = 0; j < EPT; ++j) mykey[j] = tid + j * NT < size ? keys[b0 + tid + j * NT] : 0;
     ST_BEGIN();
+#ifdef KSP_FKTIME
+    const bool st_probe = st_time[63] != 0;   // (ksp_debug_sttime(out, 2) switches the probe waits on)
+#endif
     while (b < nbuckets) {
         if (raw > HB_CAP && tid == 0) {   // left to k_bucket_big (overflow[1] counts them)
             const u32 q = atomicAdd(&overflow[1], 1u);
@@ -583,6 +591,9 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
         }
         __syncthreads();
         ST_T(35);
+#ifdef KSP_FKTIME
+        if (st_probe) { __builtin_amdgcn_s_waitcnt(0x0F70); ST_T(37); }   // (probe: what the next keys still need here)
+#endif
 #pragma unroll
         for (u32 j = 0; j < EPT; ++j) {
             const u32 i = tid + j * NT;
@@ -596,6 +607,9 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
             }
             rec[b0 + i] = (unsigned short)r;
         }
+#ifdef KSP_FKTIME
+        if (st_probe) { ST_T(38); __builtin_amdgcn_s_waitcnt(0x0F70); ST_T(39); }   // (probe: the acknowledgement of the record stores)
+#endif
         b = bn; b0 = n0; raw = nraw; size = nsize;
         {
             const u32 ua = __builtin_amdgcn_readfirstlane(la), ub = __builtin_amdgcn_readfirstlane(lb);
@@ -607,6 +621,7 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
         __syncthreads();
         ST_T(36);   // the table is rebuilt from here on
     }
+    ST_END(32);
 }
 
 // Buckets above HB_CAP entries — a key held by thousands of sources lands in one — one workgroup each, with no
@@ -1051,6 +1066,7 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
         if (lane == 0) gsum[r] = (u64)groups | ((u64)bigs << 32);
     }
     ST_T(20);
+    ST_END(16);
 }
 // crank[] from a per-entry rank array (the sort path and the postings input produce one) / the per-entry array from
 // first[] (the sort-by-block fallback after a grouping that only wrote crank[])

@@ -21,7 +21,8 @@ L = engine.lib()
 buf = (ctypes.c_ulonglong * 64)()
 for _ in range(3):
     e.build_blocks(dk.ptr.value, sk.offsets)
-L.ksp_debug_sttime(buf, 1)
+probe = 2 if os.environ.get("ST_PROBE") else 1
+L.ksp_debug_sttime(buf, probe)
 reps = 5
 for _ in range(reps):
     e.build_blocks(dk.ptr.value, sk.offsets)
@@ -31,9 +32,12 @@ print(f"{cfg}: build {e.stats()['ms_build']:.3f} ms")
 KERNELS = [("k_key_groups", 16, ["bounds: crank / first loads", "staging: tags -> new indices -> LDS + barrier", "thread-per-key walks",
                                  "barrier", "wave-per-key keys"]),
            ("k_bucket_group (per bucket pass)", 32, ["table init + barrier", "inserts + next keys issued + barrier", "slot scan + barrier",
-                                                      "offsets written + barrier", "placement + records stored + end barrier"]),
-           ("k_seg_scatter", 48, ["segment table + scan + barrier", "tile size + barrier", "bisection + key loads + bucket counts + barrier",
-                                  "bucket starts / reservations + barrier", "LDS scatter + barrier", "", "", "", "runs written out"])]
+                                                      "offsets written + barrier", "placement + records stored + end barrier",
+                                                      "(probe) wait for the next keys before the placement", "(probe) placement + record stores issued",
+                                                      "(probe) wait for the record stores"]),
+           ("k_seg_scatter", 48, ["segment table + scan + barrier", "tile size + barrier", "segment search + key loads + bucket counts + barrier: the barrier",
+                                  "bucket starts / reservations + barrier", "LDS scatter + barrier", "  (of stage 3) segment of every entry", "  (of stage 3) key loads issued and waited for",
+                                  "  (of stage 3) bucket + LDS counts (the rest: barrier)", "runs written out"])]
 for name, base, stages in KERNELS:
     n = len(stages)
     x = t[base:base + n]
