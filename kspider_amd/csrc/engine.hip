@@ -1496,11 +1496,16 @@ static int build_schedule(ksp_engine* e) {
         tile_decode(e->act_tid[i], nb, I, J);
         u64 sp = (cost[i] + target - 1) / target;
         sp = std::min<u64>(std::max<u64>(sp, 1), 32);
+        // a share that counts fewer than 2^16 keys keeps 16-bit counters whatever its blocks hold (k_join: the shares of a
+        // tile meet in the tile's 32-bit buffer): the diagonal tile of a block with a source of >= 2^16 k-mers is cut finer
+        if (I == J && !e->weighted && e->h_blk_max[I] >= 65536u && words_of(I) >= 65536u && !std::getenv("KSP_DEBUG_NO16CUT"))
+            sp = std::max<u64>(sp, std::min<u64>(words_of(I) / 65535u + 1, 256));
         if (e->matches_on && I != J) {
             // a share of records, not of estimated cycles: a round of 512 records is a chain of memory round trips,
             // and a few tiles hold most of the records (the blocks of the largest sketches) — as one workgroup each
             // they were the whole join (C4: 16 of 19 ms)
-            const u64 per_share = std::min<u64>(std::max<u64>(e->n_matches / ((u64)e->slots * 4) + 1, 8192), 1u << 20);
+            u64 per_share = std::min<u64>(std::max<u64>(e->n_matches / ((u64)e->slots * 4) + 1, 8192), 1u << 20);
+            if (e->h_blk_max[I] >= 65536u && e->h_blk_max[J] >= 65536u && !std::getenv("KSP_DEBUG_NO16CUT")) per_share = std::min<u64>(per_share, 65535);   // (16-bit counters: above)
             sp = std::min<u64>(std::max<u64>(((u64)(ms[i + 1] - ms[i]) + per_share - 1) / per_share, 1), 1024);
         }
         u32* r = &e->act_rec[4 * i];

@@ -1070,27 +1070,32 @@ __device__ __forceinline__ void join_workgroup(const JoinArgs& a, u32& I, u32& J
         if (I == J && sub != 0) return;   // (dense mode) a diagonal tail tile is done by its first share alone
         if (I == J) sp = 1;
     }
-    // 16-bit counters are exact when no pair of the tile can share 2^16 keys: one of the two blocks has no source with
-    // >= 2^16 k-mers (shared <= min(n_a, n_b)) — or, unweighted (every key counts 1), the tile itself offers fewer keys:
-    // an off-diagonal tile of the match-list join holds one record per key both blocks have, any other tile cannot count
-    // more keys than the shorter of its two lists holds.  (Metagenome bins: a block of 128 bins nearly always holds one of
-    // >= 2^16 hashes, so half the tiles took the 32-bit instantiation — 64 KB of LDS, two workgroups per CU, 9.2 of 13.5 ms —
-    // although a pair of unrelated bins shares a few hundred keys.)
-    {
-        u32 lim = min(a.blk_max[I], a.blk_max[J]);
-        if (!W) {
-            const u32 kI = a.blk_raw[I + 1] - a.blk_raw[I], kJ = a.blk_raw[J + 1] - a.blk_raw[J];
-            lim = min(lim, (a.mrec != nullptr && I != J) ? mr1 - mr0 : min(kI, kJ));
-        }
-        if ((lim < 65536u) != C16) return;
-    }
-
     const bool matches = !W && a.mrec != nullptr && I != J;
     if (matches) {   // this share's slice of the tile's records
         const u32 n = mr1 - mr0;
         mr1 = mr0 + (u32)(((u64)n * (sub + 1)) / sp);
         mr0 = mr0 + (u32)(((u64)n * sub) / sp);
     }
+    // 16-bit counters are exact when no pair can reach 2^16 in THIS SHARE: one of the two blocks has no source with
+    // >= 2^16 k-mers (shared <= min(n_a, n_b)) — or, unweighted (every key counts 1), the share itself offers fewer keys:
+    // a share of an off-diagonal tile of the match-list join holds one record per key both blocks have, a share of a
+    // diagonal tile a range of the block's keys, any other tile cannot count more keys than the shorter of its two lists
+    // holds.  The shares of a tile add their counters into the tile's 32-bit buffer, so only a share has to stay below
+    // 2^16, not the tile (the host cuts the shares of big blocks accordingly).  (Metagenome bins: a block of 128 bins
+    // nearly always holds one of >= 2^16 hashes, so half the tiles took the 32-bit instantiation — 64 KB of LDS, two
+    // workgroups per CU, 9.2 of 13.5 ms — although a pair of unrelated bins shares a few hundred keys.)
+    {
+        u32 lim = min(a.blk_max[I], a.blk_max[J]);
+        if (!W) {
+            const u32 kI = a.blk_raw[I + 1] - a.blk_raw[I], kJ = a.blk_raw[J + 1] - a.blk_raw[J];
+            const u32 mine = matches ? mr1 - mr0
+                           : I == J  ? (u32)(((u64)kI * (sub + 1)) / sp) - (u32)(((u64)kI * sub) / sp)
+                                     : min(kI, kJ);
+            lim = min(lim, mine);
+        }
+        if ((lim < 65536u) != C16) return;
+    }
+
     const bool popc = !W && a.collect && (I == J || CELLS);
     if (popc) {
         // unweighted tiles: bit-sliced accumulation in registers (no counter tile, no LDS atomics)

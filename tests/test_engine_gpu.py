@@ -97,9 +97,14 @@ def test_identical_sketches_dense_overlap(oracle_lib):
     assert len(edges) == 140 * 139 // 2
 
 
-def test_huge_sketches_use_32bit_counters(oracle_lib):
+@pytest.mark.parametrize("cut16", [True, False])
+def test_huge_sketches_use_32bit_counters(oracle_lib, monkeypatch, cut16):
     """Pairs of sources with >= 2^16 k-mers can share >= 2^16 of them: those tiles must take
-    the 32-bit counter kernel (the packed 16-bit tile would overflow)."""
+    the 32-bit counter kernel (the packed 16-bit tile would overflow) — or be cut into shares of
+    fewer than 2^16 keys each, which meet in the tile's 32-bit buffer (KSP_DEBUG_NO16CUT=1: the
+    host does not cut for that, the whole tile counts in 32 bits)."""
+    if not cut16:
+        monkeypatch.setenv("KSP_DEBUG_NO16CUT", "1")
     rng = np.random.default_rng(11)
     big = np.unique(rng.integers(1, 1 << 60, size=90000, dtype=np.uint64))
     runs = []
