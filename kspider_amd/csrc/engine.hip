@@ -196,6 +196,13 @@ struct ksp_engine {
     u64 h_scal_words = 0, h_scal_keys = 0;   // list words / distinct shared keys of the lists being finished
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // build, join, first radix sort
     hipEvent_t ev_join_done = nullptr;   // behind the count copy of the last ksp_engine_join_launch
+    // early work list (ksp_engine_step_launch): the tile flags and block tables leave for the host BEHIND the histogram of
+    // the stable split and IN FRONT of its placement pass — the host cuts the join's shares while k_ms_place / k_cidx run,
+    // and the join is queued behind them before they end (no idle device between a build and its join)
+    hipEvent_t ev_sched = nullptr;
+    bool early_ok = false;        // the caller queues the join itself right after the build (step_launch)
+    bool sched_early = false;     // this build did it
+    bool build_ms_pending = false;   // st.ms_build is read off ev[0] / ev[1] once the build's last kernel has ended
     hipEvent_t ev_rb = nullptr;          // behind a read-back the host waits for while later kernels are already queued
     double kept_frac = 0.7;              // kept / all entries of the previous build (label sampling before the count is known)
     double piece_ratio = 0;              // ksp_engine_join_to_host: densest found / bound ratio of the engine's previous call (first piece's size)
@@ -315,6 +322,24 @@ static inline void zero_add(ZeroList& z, void* p, size_t bytes) {
     z.p[z.n] = (u32*)p;
     z.words[z.n] = (u32)((bytes + 3) / 4);
     ++z.n;
+}
+
+static int launch_sched_kernels(ksp_engine* e, hipStream_t st);
+static int stage_block_tables(ksp_engine* e, hipStream_t st);
+// match records for the join (launch_sched_kernels): sparse sharing — few holders per list word
+static bool sched_wants_matches(const ksp_engine* e, const u64 K, const bool ranked) {
+    const char* jm = std::getenv("KSP_JOIN");
+    const bool force = jm && std::string(jm) == "matches", never = jm && std::string(jm) != "matches";
+    return ranked && !e->weighted && !never && K < (1ull << 31) && (force || e->n_kept < 4 * K);
+}
+// st.ms_build of a build whose work list left early: the build's last kernel has ended by the time anybody asks
+static hipError_t resolve_build_ms(ksp_engine* e) {
+    if (!e->build_ms_pending) return hipSuccess;
+    e->build_ms_pending = false;
+    hipError_t qe;
+    while ((qe = hipEventQuery(e->ev[1])) == hipErrorNotReady) {}
+    if (qe != hipSuccess) return qe;
+    return hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]);
 }
 
 template <class V>
@@ -1114,6 +1139,19 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                 else hipLaunchKernelGGL(k_ms_hist<1024>, dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, scal, hist);
                 hipLaunchKernelGGL(k_ms_scan, dim3(nb), dim3(256), 0, st, hist, mb, scal, tot, blk_raw, blk_pos, nb);
                 hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
+                // early work list (step_launch): everything the host needs to cut the join's shares exists now — the records in
+                // rank order (tile flags), the diagonal work, the list offsets — and leaves for pinned memory in front of the
+                // placement pass; the host works while k_ms_place and k_cidx run
+                e->sched_early = false;
+                if (e->early_ok && phase == 0 && !e->profiling && e->n_kept && !sched_wants_matches(e, K, true) && !std::getenv("KSP_DEBUG_LATE_SCHED")) {
+                    e->have_rank_pairs = true;
+                    e->h_scal_words = e->h_scal[1];
+                    e->h_scal_keys = e->h_scal[2];
+                    if ((rc = launch_sched_kernels(e, st))) return rc;
+                    if ((rc = stage_block_tables(e, st))) return rc;
+                    KSP_HIP(hipEventRecord(e->ev_sched, st));
+                    e->sched_early = true;
+                }
                 uint4* pm = nullptr;
                 if (!W && m >= 4 * K) {   // unweighted lists with multi-source postings (no match records: the rule of
                                           // launch_sched_kernels): the join's bit-sliced paths read the masks at the list positions
@@ -1223,6 +1261,28 @@ static int build_dispatch(ksp_engine* e, const u64* d_keys, const u32* d_w, hipS
     return build_impl<u32>(e, d_keys, d_w, st, phase);
 }
 
+// host-side bookkeeping once the full block lists sit in the engine's arrays
+// per-block maxima and list offsets to pinned host memory, in stream order (before the build's last synchronisation:
+// finish_build then reads them without a copy of its own)
+static int stage_block_tables(ksp_engine* e, hipStream_t st) {
+    const size_t bytes = ((size_t)e->nb + 1) * 4;
+    if (e->h_blk_stage_bytes < 3 * bytes) {
+        if (e->h_blk_stage) (void)hipHostFree(e->h_blk_stage);
+        e->h_blk_stage = nullptr; e->h_blk_stage_bytes = 0;
+        KSP_HIP(hipHostMalloc((void**)&e->h_blk_stage, 3 * bytes + 4096));
+        e->h_blk_stage_bytes = 3 * bytes + 4096;
+    }
+    // [maxima | sources before every block (padded layouts)], then the list offsets
+    {
+        CopyList c{};
+        copy_add(c, e->blk_max.p, e->h_blk_stage, e->padded ? 2 * bytes : bytes);
+        copy_add(c, e->blk_raw.p, e->h_blk_stage + 2 * bytes, bytes);
+        hipLaunchKernelGGL(k_copy_regions, dim3(16), dim3(256), 0, st, c);
+    }
+    e->blk_staged = true;
+    return KSP_OK;
+}
+
 // Last step of stage 1 (single build and assemble alike): the bitmap of block pairs that share a
 // key and the pair-update count of every diagonal tile; finish_build turns them into the work list.
 static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
@@ -1275,9 +1335,7 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     e->matches_on = false;
     e->n_matches = 0;
     {
-        const char* jm = std::getenv("KSP_JOIN");
-        const bool force = jm && std::string(jm) == "matches", never = jm && std::string(jm) != "matches";
-        if (ranked && !e->weighted && !never && K < (1ull << 31) && (force || e->n_kept < 4 * K)) {
+        if (sched_wants_matches(e, K, ranked)) {
             phase_mark(e, st, "match records");
             if ((rc = e->mcnt.ensure((K + 4) * 4))) return rc;
             if ((rc = e->moff.ensure((K + 4) * 8))) return rc;
@@ -1357,6 +1415,7 @@ int ksp_engine_create(int device, ksp_engine** out) {
     if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_scal, 128);
     for (int i = 0; i < 6 && err == hipSuccess; ++i) err = hipEventCreate(&e->ev[i]);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_join_done);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_sched, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_rb, hipEventDisableTiming);
     for (int i = 0; i < ksp_engine::kMaxPhase && err == hipSuccess; ++i) err = hipEventCreate(&e->ph_ev[i]);
     if (err != hipSuccess) {
@@ -1387,6 +1446,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     if (e->h_blk_stage) (void)hipHostFree(e->h_blk_stage);
     for (int i = 0; i < 6; ++i) if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     if (e->ev_join_done) (void)hipEventDestroy(e->ev_join_done);
+    if (e->ev_sched) (void)hipEventDestroy(e->ev_sched);
     if (e->ev_rb) (void)hipEventDestroy(e->ev_rb);
     for (int i = 0; i < ksp_engine::kMaxPhase; ++i) if (e->ph_ev[i]) (void)hipEventDestroy(e->ph_ev[i]);
     delete e;
@@ -1545,28 +1605,6 @@ static int build_schedule(ksp_engine* e) {
     return KSP_OK;
 }
 
-// host-side bookkeeping once the full block lists sit in the engine's arrays
-// per-block maxima and list offsets to pinned host memory, in stream order (before the build's last synchronisation:
-// finish_build then reads them without a copy of its own)
-static int stage_block_tables(ksp_engine* e, hipStream_t st) {
-    const size_t bytes = ((size_t)e->nb + 1) * 4;
-    if (e->h_blk_stage_bytes < 3 * bytes) {
-        if (e->h_blk_stage) (void)hipHostFree(e->h_blk_stage);
-        e->h_blk_stage = nullptr; e->h_blk_stage_bytes = 0;
-        KSP_HIP(hipHostMalloc((void**)&e->h_blk_stage, 3 * bytes + 4096));
-        e->h_blk_stage_bytes = 3 * bytes + 4096;
-    }
-    // [maxima | sources before every block (padded layouts)], then the list offsets
-    {
-        CopyList c{};
-        copy_add(c, e->blk_max.p, e->h_blk_stage, e->padded ? 2 * bytes : bytes);
-        copy_add(c, e->blk_raw.p, e->h_blk_stage + 2 * bytes, bytes);
-        hipLaunchKernelGGL(k_copy_regions, dim3(16), dim3(256), 0, st, c);
-    }
-    e->blk_staged = true;
-    return KSP_OK;
-}
-
 static int finish_build(ksp_engine* e) {
     e->st.key_bits = e->key_bits;
     if (e->blk_staged) {
@@ -1658,6 +1696,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     if (n == 0 || e->nb == 0) return KSP_OK;   // nothing can intersect
     int rc;
     if ((rc = e->d_off.ensure(((size_t)n_sources + 1) * 8))) return rc;
+    KSP_HIP(resolve_build_ms(e));   // (the previous build's time, before its events are recorded again)
     KSP_HIP(hipEventRecord(e->ev[0], st));
     if (!same_offsets) {   // (the engine's own copy is the source: the caller's array may go away before the copy has run)
         KSP_HIP(hipMemcpyAsync(e->d_off.p, e->h_off.data(), ((size_t)n_sources + 1) * 8, hipMemcpyHostToDevice, st));
@@ -1680,6 +1719,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     for (int attempt = 0; attempt < 2; ++attempt) {
         const int phase = slice ? 1 : 0;   // a slice stops at the source labels (ksp_engine_slice_finish does the rest)
         e->scal_fresh = false;
+        e->sched_early = false;
         rc = build_dispatch(e, d_keys, d_weights, st, phase);
         if (rc) return rc;
         if (!e->scal_fresh) {   // (the key-by-key list build has read [1] .. [11] back already: nothing changes them after)
@@ -1691,8 +1731,8 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
         // redo with a full-width sort and remember it for later builds on this engine
         e->full_sort = true;
     }
-    e->have_bits = false;
-    if (!slice && e->n_kept) {   // the work list of the join (slices: after the assemble)
+    if (!e->sched_early) e->have_bits = false;
+    if (!slice && e->n_kept && !e->sched_early) {   // the work list of the join (slices: after the assemble)
         e->h_scal_words = e->h_scal[1];
         e->h_scal_keys = e->h_scal[2];
         if ((rc = launch_sched_kernels(e, st))) return rc;
@@ -1702,12 +1742,18 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     // (polling the event instead of a blocking wait: the join cannot be cut into shares before the build's tables have
     //  landed, and waking a blocked host thread is tens of microseconds of device idle time per step)
     {
+        const hipEvent_t landed = e->sched_early ? e->ev_sched : e->ev[1];   // (early work list: the placement pass is still running)
         hipError_t qe;
-        while ((qe = hipEventQuery(e->ev[1])) == hipErrorNotReady) {}
+        while ((qe = hipEventQuery(landed)) == hipErrorNotReady) {}
         KSP_HIP(qe);
     }
-    KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
-    phase_close(e, e->ev[1]);
+    if (e->sched_early) {
+        e->build_ms_pending = true;   // (read off the events by whoever asks first: ksp_engine_get_stats, the join's wait, the next build)
+        e->st.ms_build = 0;
+    } else {
+        KSP_HIP(hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]));
+        phase_close(e, e->ev[1]);
+    }
     e->st.key_bits = e->key_bits;
     e->st.ms_sort = 0;
     e->st.sort_entries = e->sort_entries;
@@ -1769,6 +1815,7 @@ static int build_postings_common(ksp_engine* e, const uint64_t* h_key_off, const
         return KSP_OK;
     }
     int rc;
+    KSP_HIP(resolve_build_ms(e));   // (the previous build's time, before its events are recorded again)
     KSP_HIP(hipEventRecord(e->ev[0], st));
     {   // fine cells as in build_common, from the mean block size (the holders are not grouped by source here)
         const u64 dmax = 2 * (n / e->nb + 1);
@@ -1884,6 +1931,7 @@ int ksp_engine_slice_finish(ksp_engine* e, const uint32_t* d_labels, void* strea
     e->slice_phase = 0;
     if (e->n_entries == 0 || e->nb == 0) { e->slice_ready = true; return KSP_OK; }
     int rc;
+    KSP_HIP(resolve_build_ms(e));   // (the previous build's time, before its events are recorded again)
     KSP_HIP(hipEventRecord(e->ev[0], st));
     if (d_labels) KSP_HIP(hipMemcpyAsync(label_array(e), d_labels, (size_t)e->n_sources * 4, hipMemcpyDeviceToDevice, st));
     rc = build_dispatch(e, nullptr, nullptr, st, 2);
@@ -1979,6 +2027,7 @@ int ksp_engine_assemble(ksp_engine* e, uint32_t nparts, const uint64_t* h_sizes 
     if (e->weighted && (rc = e->bw.ensure(lmax * 4))) return rc;
     if ((rc = e->mm.ensure((bigtot + 16) * 16))) return rc;
     if ((rc = e->asm_small.ensure(off.size() * 4))) return rc;
+    KSP_HIP(resolve_build_ms(e));   // (the previous build's time, before its events are recorded again)
     KSP_HIP(hipEventRecord(e->ev[0], st));
     KSP_HIP(hipMemcpyAsync(e->asm_small.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, st));
     u64* scal = e->scalars.as<u64>();
@@ -2426,7 +2475,9 @@ int ksp_engine_step_launch(ksp_engine* e, const uint64_t* d_keys, const uint32_t
     if (prev_ms_join) *prev_ms_join = 0;
     const bool had_join = e && e->join_pending;
     const u64 had_cap = e ? e->join_cap : 0;
+    if (e) e->early_ok = true;   // (the join follows at once, on the same stream: the work list may leave the build early)
     int rc = ksp_engine_build_blocks(e, d_keys, d_weights, h_offsets, n_sources, key_bits, stream);
+    if (e) e->early_ok = false;
     if (rc) return rc;
     if (had_join) {   // the join launched before this build ran in front of it on the stream: its count is there
         e->join_pending = true;
@@ -2458,6 +2509,7 @@ int ksp_engine_phase_times(const ksp_engine* e, const char** names, float* ms, i
 
 int ksp_engine_get_stats(const ksp_engine* e, ksp_stats* out) {
     if (!e || !out) return KSP_E_ARG;
+    KSP_HIP(resolve_build_ms(const_cast<ksp_engine*>(e)));
     *out = e->st;
     return KSP_OK;
 }
