@@ -1138,10 +1138,10 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                 if (mb == 256) hipLaunchKernelGGL(k_ms_hist<256>, dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, scal, hist);
                 else hipLaunchKernelGGL(k_ms_hist<1024>, dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, scal, hist);
                 hipLaunchKernelGGL(k_ms_scan, dim3(nb), dim3(256), 0, st, hist, mb, scal, tot, blk_raw, blk_pos, nb);
-                hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
                 // early work list (step_launch): everything the host needs to cut the join's shares exists now — the records in
                 // rank order (tile flags), the diagonal work, the list offsets — and leaves for pinned memory in front of the
-                // placement pass; the host works while k_ms_place and k_cidx run
+                // placement pass; the host works while k_ms_place and k_cidx run.  (On a stream of its own, beside the placement
+                // pass, the hand-over between the streams cost more than the four small kernels: 1.334 against 1.320 ms per step.)
                 e->sched_early = false;
                 if (e->early_ok && phase == 0 && !e->profiling && e->n_kept && !sched_wants_matches(e, K, true) && !std::getenv("KSP_DEBUG_LATE_SCHED")) {
                     e->have_rank_pairs = true;
@@ -1160,10 +1160,10 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                 }
                 if (mb == 256)
                     hipLaunchKernelGGL((k_ms_place<W, 256>), dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, rec_val, scal, hist, blk_pos, nb, wkey,
-                                       e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, e->mm.as<uint4>(), pm);
+                                       e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, e->mm.as<uint4>(), pm, blk_raw, PAD);
                 else
                     hipLaunchKernelGGL((k_ms_place<W, 1024>), dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, rec_val, scal, hist, blk_pos, nb, wkey,
-                                       e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, e->mm.as<uint4>(), pm);
+                                       e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, e->mm.as<uint4>(), pm, blk_raw, PAD);
                 e->pmask_on = pm != nullptr;
             } else {
             tb = 0;   // (temporary storage for the bound, not for this build's K: K moves a little from build to build — the labels'

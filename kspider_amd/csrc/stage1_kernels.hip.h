@@ -1370,15 +1370,22 @@ __global__ __launch_bounds__(MS_THREADS) void k_ms_place(const u32* __restrict__
                                                           const u64* __restrict__ scal, const u32* __restrict__ base,
                                                           const u32* __restrict__ blk_pos, const u32 nb, const u32* __restrict__ wkey,
                                                           u32* __restrict__ brk, u32* __restrict__ info, u32* __restrict__ bw,
-                                                          const uint4* __restrict__ bigmask, uint4* __restrict__ pmask) {
+                                                          const uint4* __restrict__ bigmask, uint4* __restrict__ pmask,
+                                                          const u32* __restrict__ blk_raw, const u32 padv) {
     constexpr u32 NWV = MS_THREADS / 64, NSL = MS_ROUNDS * NWV, BITS = MB == 256 ? 8u : 10u;
     static_assert(MB == 256 || MB == 1024, "two table sizes");
     __shared__ unsigned short s_cnt[NSL][MB];   // records of block b in (round, wave) slot (<= 64); then: records before the slot (< 2 048)
     __shared__ u32 s_dst[MB];                   // first place of this chunk's records of block b in the padded list
     const u32 n = (u32)scal[1];
     const u32 g0 = blockIdx.x * MS_CHUNK;
-    if (g0 >= n) return;
     const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // (k_pad's work — the padding words behind every block's list and behind the last block — rides along: a dispatch less)
+    for (u32 b = blockIdx.x; b <= nb; b += gridDim.x) {
+        const u32 lo = b < nb ? blk_pos[b] + (blk_raw[b + 1] - blk_raw[b]) : blk_pos[nb];
+        const u32 hi = b < nb ? blk_pos[b + 1] : blk_pos[nb] + 4u * WIN;
+        for (u32 i = lo + tid; i < hi; i += MS_THREADS) brk[i] = padv;
+    }
+    if (g0 >= n) return;
     for (u32 i = tid; i < NSL * MB / 2; i += MS_THREADS) reinterpret_cast<u32*>(&s_cnt[0][0])[i] = 0;
     for (u32 i = tid; i < MB; i += MS_THREADS) s_dst[i] = (i < nb ? blk_pos[i] : 0u) + base[(size_t)blockIdx.x * MB + i];
     u32 blk[MS_ROUNDS], rk[MS_ROUNDS];
