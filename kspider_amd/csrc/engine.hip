@@ -310,6 +310,15 @@ __global__ void k_copy_regions(const CopyList c) {
     for (int r = 0; r < c.n; ++r)
         for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < c.words[r]; i += gridDim.x * blockDim.x) c.dst[r][i] = c.src[r][i];
 }
+// the tile flags packed straight into pinned host memory, and a few small regions copied out by the same launch (the
+// work list's inputs leave the device in one dispatch instead of three: k_pack_flags, two k_copy_regions)
+__global__ void k_pack_flags_out(const unsigned char* __restrict__ flags, const u64 n, u32* __restrict__ bits_out, const CopyList c) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;   // blockDim is a multiple of 64
+    const unsigned long long m = __ballot(t < n && flags[t] != 0);
+    if ((threadIdx.x & 63) == 0 && t < n) { bits_out[t >> 5] = (u32)m; bits_out[(t >> 5) + 1] = (u32)(m >> 32); }
+    for (int r = 0; r < c.n; ++r)
+        for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < c.words[r]; i += gridDim.x * blockDim.x) c.dst[r][i] = c.src[r][i];
+}
 static inline void copy_add(CopyList& c, const void* src, void* dst, size_t bytes) {
     if (!bytes) return;
     c.src[c.n] = (const u32*)src;
@@ -324,7 +333,7 @@ static inline void zero_add(ZeroList& z, void* p, size_t bytes) {
     ++z.n;
 }
 
-static int launch_sched_kernels(ksp_engine* e, hipStream_t st);
+static int launch_sched_kernels(ksp_engine* e, hipStream_t st, bool with_tables = false);
 static int stage_block_tables(ksp_engine* e, hipStream_t st);
 // match records for the join (launch_sched_kernels): sparse sharing — few holders per list word
 static bool sched_wants_matches(const ksp_engine* e, const u64 K, const bool ranked) {
@@ -1147,8 +1156,8 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                     e->have_rank_pairs = true;
                     e->h_scal_words = e->h_scal[1];
                     e->h_scal_keys = e->h_scal[2];
-                    if ((rc = launch_sched_kernels(e, st))) return rc;
-                    if ((rc = stage_block_tables(e, st))) return rc;
+                    if ((rc = launch_sched_kernels(e, st, true))) return rc;
+                    if (!e->blk_staged && (rc = stage_block_tables(e, st))) return rc;
                     KSP_HIP(hipEventRecord(e->ev_sched, st));
                     e->sched_early = true;
                 }
@@ -1264,7 +1273,7 @@ static int build_dispatch(ksp_engine* e, const u64* d_keys, const u32* d_w, hipS
 // host-side bookkeeping once the full block lists sit in the engine's arrays
 // per-block maxima and list offsets to pinned host memory, in stream order (before the build's last synchronisation:
 // finish_build then reads them without a copy of its own)
-static int stage_block_tables(ksp_engine* e, hipStream_t st) {
+static int block_table_regions(ksp_engine* e, CopyList& c) {
     const size_t bytes = ((size_t)e->nb + 1) * 4;
     if (e->h_blk_stage_bytes < 3 * bytes) {
         if (e->h_blk_stage) (void)hipHostFree(e->h_blk_stage);
@@ -1273,19 +1282,22 @@ static int stage_block_tables(ksp_engine* e, hipStream_t st) {
         e->h_blk_stage_bytes = 3 * bytes + 4096;
     }
     // [maxima | sources before every block (padded layouts)], then the list offsets
-    {
-        CopyList c{};
-        copy_add(c, e->blk_max.p, e->h_blk_stage, e->padded ? 2 * bytes : bytes);
-        copy_add(c, e->blk_raw.p, e->h_blk_stage + 2 * bytes, bytes);
-        hipLaunchKernelGGL(k_copy_regions, dim3(16), dim3(256), 0, st, c);
-    }
+    copy_add(c, e->blk_max.p, e->h_blk_stage, e->padded ? 2 * bytes : bytes);
+    copy_add(c, e->blk_raw.p, e->h_blk_stage + 2 * bytes, bytes);
     e->blk_staged = true;
+    return KSP_OK;
+}
+static int stage_block_tables(ksp_engine* e, hipStream_t st) {
+    CopyList c{};
+    int rc = block_table_regions(e, c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_copy_regions, dim3(16), dim3(256), 0, st, c);
     return KSP_OK;
 }
 
 // Last step of stage 1 (single build and assemble alike): the bitmap of block pairs that share a
 // key and the pair-update count of every diagonal tile; finish_build turns them into the work list.
-static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
+static int launch_sched_kernels(ksp_engine* e, hipStream_t st, const bool with_tables) {
     e->have_bits = false;
     e->sched_stream = st;
     const u32 nb = e->nb;
@@ -1329,7 +1341,8 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
         KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, pr, pr2, pb, pb2, (size_t)K, 0, rbits, st));
     }
     if (!fused) hipLaunchKernelGGL(k_tile_flags, dim3(grid_for(K, 256)), dim3(256), 0, st, pr2, pb2, K, nb, flags);
-    hipLaunchKernelGGL(k_pack_flags, dim3(grid_for(T, 256)), dim3(256), 0, st, flags, T, e->tbits.as<u32>());
+    const bool direct = T <= (1ull << 20);   // (a larger bitmap goes through device memory: one copy instead of 8-byte stores over PCIe)
+    if (!direct) hipLaunchKernelGGL(k_pack_flags, dim3(grid_for(T, 256)), dim3(256), 0, st, flags, T, e->tbits.as<u32>());
     // match records for the join (sparse sharing: few holders per list word — the lists are long and a block pair
     // matches next to nothing of them; KSP_JOIN=matches / search forces the choice)
     e->matches_on = false;
@@ -1375,8 +1388,10 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st) {
     {
         CopyList c{};
         copy_add(c, e->dwork.p, e->h_stage, ((size_t)nb + 2) * 8);
-        copy_add(c, e->tbits.p, e->h_stage + ((size_t)nb + 2) * 8, bit_words * 4);
-        hipLaunchKernelGGL(k_copy_regions, dim3(64), dim3(256), 0, st, c);
+        if (!direct) copy_add(c, e->tbits.p, e->h_stage + ((size_t)nb + 2) * 8, bit_words * 4);
+        if (with_tables && (rc = block_table_regions(e, c))) return rc;   // (the per-block maxima and list offsets ride along)
+        if (direct) hipLaunchKernelGGL(k_pack_flags_out, dim3(grid_for(T, 256)), dim3(256), 0, st, flags, T, reinterpret_cast<u32*>(e->h_stage + ((size_t)nb + 2) * 8), c);
+        else hipLaunchKernelGGL(k_copy_regions, dim3(64), dim3(256), 0, st, c);
     }
     KSP_HIP(hipGetLastError());
     e->have_bits = true;
@@ -1735,8 +1750,8 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     if (!slice && e->n_kept && !e->sched_early) {   // the work list of the join (slices: after the assemble)
         e->h_scal_words = e->h_scal[1];
         e->h_scal_keys = e->h_scal[2];
-        if ((rc = launch_sched_kernels(e, st))) return rc;
-        if ((rc = stage_block_tables(e, st))) return rc;
+        if ((rc = launch_sched_kernels(e, st, true))) return rc;
+        if (!e->blk_staged && (rc = stage_block_tables(e, st))) return rc;
     }
     KSP_HIP(hipEventRecord(e->ev[1], st));
     // (polling the event instead of a blocking wait: the join cannot be cut into shares before the build's tables have
