@@ -34,7 +34,12 @@ if mode == "load":
     z = np.load(path)
     sk = synth.SketchSet(z["keys"], z["offsets"], z["cluster"], cfg)
 else:
-    sk = synth.generate(cfg)
+    kw = {}
+    if os.environ.get("PROF_SOURCES"):   # (a variant of the configuration: PROF_SOURCES=50000 PROF_MEAN=10000)
+        kw["n_sources"] = int(os.environ["PROF_SOURCES"])
+    if os.environ.get("PROF_MEAN"):
+        kw["mean_size"] = int(os.environ["PROF_MEAN"])
+    sk = synth.generate(cfg, **kw)
     if mode == "dump":
         np.savez(path, keys=sk.keys, offsets=sk.offsets, cluster=sk.cluster)
         print(f"[prof_step {cfg}] dumped to {path}", flush=True)
@@ -46,7 +51,11 @@ de = None
 out = {}
 builds, joins = [], []
 for s in range(steps):
+    if os.environ.get("PROF_PHASES") and s == steps - 1:   # (the last step with an event per phase: where the build's time goes)
+        e.set_profiling(True)
     e.build_blocks(dk.ptr.value, sk.offsets)
+    if os.environ.get("PROF_PHASES") and s == steps - 1:
+        print(f"[prof_step {cfg}] phases: " + ", ".join(f"{n} {ms:.3f}" for n, ms in e.phase_times()), flush=True)
     T = e.num_tiles
     if de is None:
         cap = int(min(e.edge_bound(0, T), 1 << 27)) + 1
