@@ -140,7 +140,7 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_fgroup(const u64* __restrict_
             if (cnt[j] >= 2) mine += cnt[j] | (1u << 16);
         }
         u32 inc = mine;
-        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+        inc = wave_scan_add(inc);
         if (lane == 63) wpart[wv] = inc;
         __syncthreads();
         u32 run = inc - mine;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(FK_THREADS) void k_fkeys(const V* __restrict__ tags
 #pragma unroll
             for (u32 q = 0; q < 4; ++q) { c[q] = (u32)__popc(s_head[4 * lane + q]); t += c[q]; }
             u32 inc = t;
-            for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+            inc = wave_scan_add(inc);
             u32 run = inc - t;
 #pragma unroll
             for (u32 q = 0; q < 4; ++q) { s_hpre[4 * lane + q] = run; run += c[q]; }
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void k_fms_scan(u32* __restrict__ hist, const 
         for (u32 i = 0; i < MS_PER; ++i) sum += h[i];
     }
     u32 inc = sum;
-    for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+    inc = wave_scan_add(inc);
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
     u32 run = inc - sum, total = 0;

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(P1_THREADS) void k_part1(const u64* __restrict__ ke
 #pragma unroll
             for (u32 i = 0; i < 4; ++i) { c[i] = s_hist[4 * lane + i]; t += c[i]; }
             u32 inc = t;
-            for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+            inc = wave_scan_add(inc);
             u32 run = inc - t;
 #pragma unroll
             for (u32 i = 0; i < 4; ++i) { s_ls[4 * lane + i] = run; run += c[i]; }
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(1024) void k_group_base(u64* __restrict__ scal, con
         if (g < ngroups && !bad)
             for (u32 r = 0; r < pl.subs; ++r) tot += pl.cursors[(size_t)(g * pl.subs + r) * P1_LINE];
         u32 inc = tot;
-        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+        inc = wave_scan_add(inc);
         if (lane == 63) s_w[wv] = inc;
         __syncthreads();
         u32 run = s_carry + inc - tot;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_scan2(const u32* __restrict__ gbase, co
     const bool in = tid < (1u << pb2) && b < nbuckets;
     const u32 c = in ? gcnt[b] : 0u;
     u32 inc = c;
-    for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+    inc = wave_scan_add(inc);
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
     u32 run = gbase[B] + inc - c;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_scatter2(const u64* __restrict__
 #pragma unroll
         for (u32 i = 0; i < 4; ++i) { c[i] = s_cnt[4 * lane + i]; t += c[i]; }
         u32 inc = t;
-        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+        inc = wave_scan_add(inc);
         u32 run = inc - t;
 #pragma unroll
         for (u32 i = 0; i < 4; ++i) { s_ls[4 * lane + i] = run; run += c[i]; }
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_part_mid(const u64* __restrict__
 #pragma unroll
         for (u32 i = 0; i < 4; ++i) { c[i] = s_cnt[4 * lane + i]; t += c[i]; }
         u32 inc = t;
-        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+        inc = wave_scan_add(inc);
         u32 run = inc - t;
 #pragma unroll
         for (u32 i = 0; i < 4; ++i) { s_ls[4 * lane + i] = run; run += c[i]; }
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
         s_addr[tid] = (u32)off[s0 + tid] + lo;   // (fewer than 2^30 entries per build)
     }
     u32 inc = len;
-    for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+    inc = wave_scan_add(inc);
     if (lane == 63) s_w[wv] = inc;
     if (tid < 256) s_cnt[tid] = 0;
     __syncthreads();
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_scatter(const u64* __restric
 #pragma unroll
         for (u32 i = 0; i < 4; ++i) { c[i] = s_cnt[4 * lane + i]; t += c[i]; }
         u32 in2 = t;
-        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(in2, o); if ((int)lane >= o) in2 += up; }
+        in2 = wave_scan_add(in2);
         u32 r2 = in2 - t;
 #pragma unroll
         for (u32 i = 0; i < 4; ++i) { s_ls[4 * lane + i] = r2; r2 += c[i]; }
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_mid(const u64* __restrict__ 
         s_addr[tid] = (u32)off[s0 + tid] + lo;
     }
     u32 inc = len;
-    for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+    inc = wave_scan_add(inc);
     if (lane == 63) s_w[wv] = inc;
     if (tid < 256) s_cnt[tid] = 0;
     __syncthreads();
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(P2_THREADS) void k_seg_mid(const u64* __restrict__ 
 #pragma unroll
         for (u32 i = 0; i < 4; ++i) { c[i] = s_cnt[4 * lane + i]; t += c[i]; }
         u32 in2 = t;
-        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(in2, o); if ((int)lane >= o) in2 += up; }
+        in2 = wave_scan_add(in2);
         u32 r2 = in2 - t;
 #pragma unroll
         for (u32 i = 0; i < 4; ++i) { s_ls[4 * lane + i] = r2; r2 += c[i]; }

@@ -16,6 +16,19 @@ template <> __host__ __device__ inline u16 make_tag<u16>(u32 canon, u32 w) { (vo
 template <class V> __host__ __device__ inline u32 weight_of(V v) { (void)v; return 0u; }
 template <> __host__ __device__ inline u32 weight_of<u64>(u64 v) { return (u32)(v >> 32); }
 static_assert(TB == 128, "compact tags: 7-bit local ids");
+// Inclusive prefix sum over the 64 lanes of a wave on the vector unit alone: row_shr 1 / 2 / 4 / 8 inside the rows of 16
+// lanes, then the last lane of a row broadcast to the next row (row_bcast:15 on rows 1 and 3) and lane 31 to the upper
+// half (row_bcast:31).  The shuffle formulation (__shfl_up, six steps) compiles to six ds_bpermute_b32 — six dependent
+// round trips through the LDS pipe, which the workgroups of stage 1 keep busy with their own traffic.
+__device__ inline u32 wave_scan_add(u32 x) {
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
 // ------------------------------------------------------------------------------------
 // stage 1 kernels
 // ------------------------------------------------------------------------------------
@@ -573,7 +586,7 @@ __global__ __launch_bounds__(HB_THREADS, 6) void k_bucket_group(const u64* __res
             if (cnt[j] >= 2) mine += cnt[j] | (1u << 16);
         }
         u32 inc = mine;
-        for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+        inc = wave_scan_add(inc);
         if (lane == 63) wpart[wv] = inc;
         __syncthreads();
         ST_T(34);
@@ -676,11 +689,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_big(const u64* __restrict
         const u32 c = sl <= HB_SLOTS ? tcnt[sl] : 0;
         if (c >= 2) { me += c; ++mk; }
     }
-    u32 ie = me, ik = mk;
-    for (int o = 1; o < 64; o <<= 1) {
-        const u32 ue = __shfl_up(ie, o), uk = __shfl_up(ik, o);
-        if (lane >= o) { ie += ue; ik += uk; }
-    }
+    const u32 ie = wave_scan_add(me), ik = wave_scan_add(mk);
     if (lane == 63) { wpe[wv] = ie; wpk[wv] = ik; }
     __syncthreads();
     u32 re = ie - me, rk = ik - mk, te = 0, tk = 0;
@@ -767,11 +776,7 @@ __global__ __launch_bounds__(HB_THREADS) void k_bucket_emit(const unsigned short
         if (tid < 64) {   // keys in front of every word of the bitmap (96 words: two per lane of one wave)
             static_assert(FW <= 128, "two bitmap words per lane");
             const u32 c0 = lane < FW ? (u32)__popc(s_fbits[lane]) : 0u, c1 = 64 + lane < FW ? (u32)__popc(s_fbits[64 + lane]) : 0u;
-            u32 i0 = c0, i1 = c1;
-            for (int o = 1; o < 64; o <<= 1) {
-                const u32 u0 = __shfl_up(i0, o), u1 = __shfl_up(i1, o);
-                if ((int)lane >= o) { i0 += u0; i1 += u1; }
-            }
+            const u32 i0 = wave_scan_add(c0), i1 = wave_scan_add(c1);
             const u32 tot0 = __shfl(i0, 63);
             if (lane < FW) s_fpre[lane] = i0 - c0;
             if (64 + lane < FW) s_fpre[64 + lane] = tot0 + i1 - c1;
@@ -1116,7 +1121,7 @@ __global__ __launch_bounds__(256) void k_key_groups_huge(const V* __restrict__ v
         if (cnt) mine += 1u + ((cnt > INLINE_MAX) << 16);
     }
     u32 inc = mine;
-    for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if (lane >= o) inc += up; }
+    inc = wave_scan_add(inc);
     if (lane == 63) s_part[wv] = inc;
     __syncthreads();
     u32 run = inc - mine;
@@ -1326,7 +1331,7 @@ __global__ __launch_bounds__(256) void k_ms_scan(u32* __restrict__ hist, const u
         for (u32 i = 0; i < MS_PER; ++i) sum += h[i];
     }
     u32 inc = sum;
-    for (int o = 1; o < 64; o <<= 1) { const u32 up = __shfl_up(inc, o); if ((int)lane >= o) inc += up; }
+    inc = wave_scan_add(inc);
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
     u32 run = inc - sum, total = 0;
