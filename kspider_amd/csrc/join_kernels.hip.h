@@ -571,17 +571,40 @@ __device__ inline void emit_tile(const JoinArgs& a, const u32 I, const u32 J, co
 // owns a 4 x 4 patch of source pairs: per group 8 column words, 16 x popcount(a & b).  The 496
 // patches above the diagonal go to threads 0..495; the 192 pairs inside the 32 diagonal patches go
 // one each to threads 0..191.  Results leave as edges straight from registers.
-__device__ inline u64 transpose64_step(u64 x, const int lane, const int j, const u64 m) {
-    const u64 p = __shfl_xor(x, j);
-    return (lane & j) == 0 ? ((x & m) | ((p & m) << j)) : (((p >> j) & m) | (x & (m << j)));
+// The partner's word of every butterfly step comes through the vector unit (gfx950: v_permlane32_swap / v_permlane16_swap
+// across the halves and the rows of a wave, DPP row rotation / mirrors / quad permutations inside a row), not through
+// __shfl_xor — which compiles to ds_bpermute_b32: twelve dependent round trips through the LDS pipe per transpose, in a
+// kernel whose workgroups keep that pipe busy with column reads.
+template <int J>
+__device__ inline u32 xor_lane(const u32 d, const int lane) {   // d of lane ^ J
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16, "inside a half wave");
+    if (J == 1) return (u32)__builtin_amdgcn_update_dpp(0, (int)d, 0xB1, 0xf, 0xf, false);    // quad_perm:[1,0,3,2]
+    if (J == 2) return (u32)__builtin_amdgcn_update_dpp(0, (int)d, 0x4E, 0xf, 0xf, false);    // quad_perm:[2,3,0,1]
+    if (J == 4) {   // lane ^ 7 (row_half_mirror), then lane ^ 3 (quad_perm:[3,2,1,0])
+        const u32 t = (u32)__builtin_amdgcn_update_dpp(0, (int)d, 0x141, 0xf, 0xf, false);
+        return (u32)__builtin_amdgcn_update_dpp(0, (int)t, 0x1B, 0xf, 0xf, false);
+    }
+    if (J == 8) return (u32)__builtin_amdgcn_update_dpp(0, (int)d, 0x128, 0xf, 0xf, false);   // row_ror:8
+    // J == 16: the odd rows of the first operand change places with the even rows of the second; both are d
+    const auto r = __builtin_amdgcn_permlane16_swap(d, d, false, false);   // {[r0 r0 r2 r2], [r1 r1 r3 r3]}
+    return (lane & 16) ? r[0] : r[1];
+}
+template <int J>
+__device__ inline u64 transpose64_step(const u64 x, const int lane, const u64 m) {
+    const u64 p = (u64)xor_lane<J>((u32)x, lane) | ((u64)xor_lane<J>((u32)(x >> 32), lane) << 32);
+    return (lane & J) == 0 ? ((x & m) | ((p & m) << J)) : (((p >> J) & m) | (x & (m << J)));
 }
 __device__ inline u64 transpose64(u64 x, const int lane) {   // bit b of lane r  <->  bit r of lane b
-    x = transpose64_step(x, lane, 32, 0x00000000FFFFFFFFull);
-    x = transpose64_step(x, lane, 16, 0x0000FFFF0000FFFFull);
-    x = transpose64_step(x, lane, 8, 0x00FF00FF00FF00FFull);
-    x = transpose64_step(x, lane, 4, 0x0F0F0F0F0F0F0F0Full);
-    x = transpose64_step(x, lane, 2, 0x3333333333333333ull);
-    x = transpose64_step(x, lane, 1, 0x5555555555555555ull);
+    {   // step 32: lanes < 32 keep their low word and take the partner's low word as their high word, lanes >= 32 the other
+        // way round — the upper half of the low words changes places with the lower half of the high words: ONE instruction
+        const auto r = __builtin_amdgcn_permlane32_swap((u32)x, (u32)(x >> 32), false, false);
+        x = (u64)r[0] | ((u64)r[1] << 32);
+    }
+    x = transpose64_step<16>(x, lane, 0x0000FFFF0000FFFFull);
+    x = transpose64_step<8>(x, lane, 0x00FF00FF00FF00FFull);
+    x = transpose64_step<4>(x, lane, 0x0F0F0F0F0F0F0F0Full);
+    x = transpose64_step<2>(x, lane, 0x3333333333333333ull);
+    x = transpose64_step<1>(x, lane, 0x5555555555555555ull);
     return x;
 }
 // A share (sub of sp) takes a range of the block's keys; with several shares the partial counts are
