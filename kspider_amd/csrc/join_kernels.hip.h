@@ -576,20 +576,6 @@ __device__ inline void emit_tile(const JoinArgs& a, const u32 I, const u32 J, co
 // __shfl_xor — which compiles to ds_bpermute_b32: twelve dependent round trips through the LDS pipe per transpose, in a
 // kernel whose workgroups keep that pipe busy with column reads.
 template <int J>
-__device__ inline u32 xor_lane(const u32 d, const int lane) {   // d of lane ^ J
-    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16, "inside a half wave");
-    if (J == 1) return (u32)__builtin_amdgcn_update_dpp(0, (int)d, 0xB1, 0xf, 0xf, false);    // quad_perm:[1,0,3,2]
-    if (J == 2) return (u32)__builtin_amdgcn_update_dpp(0, (int)d, 0x4E, 0xf, 0xf, false);    // quad_perm:[2,3,0,1]
-    if (J == 4) {   // lane ^ 7 (row_half_mirror), then lane ^ 3 (quad_perm:[3,2,1,0])
-        const u32 t = (u32)__builtin_amdgcn_update_dpp(0, (int)d, 0x141, 0xf, 0xf, false);
-        return (u32)__builtin_amdgcn_update_dpp(0, (int)t, 0x1B, 0xf, 0xf, false);
-    }
-    if (J == 8) return (u32)__builtin_amdgcn_update_dpp(0, (int)d, 0x128, 0xf, 0xf, false);   // row_ror:8
-    // J == 16: the odd rows of the first operand change places with the even rows of the second; both are d
-    const auto r = __builtin_amdgcn_permlane16_swap(d, d, false, false);   // {[r0 r0 r2 r2], [r1 r1 r3 r3]}
-    return (lane & 16) ? r[0] : r[1];
-}
-template <int J>
 __device__ inline u64 transpose64_step(const u64 x, const int lane, const u64 m) {
     const u64 p = (u64)xor_lane<J>((u32)x, lane) | ((u64)xor_lane<J>((u32)(x >> 32), lane) << 32);
     return (lane & J) == 0 ? ((x & m) | ((p & m) << J)) : (((p >> J) & m) | (x & (m << J)));

@@ -29,6 +29,44 @@ __device__ inline u32 wave_scan_add(u32 x) {
     x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return x;
 }
+// The word of lane ^ J through the vector unit (gfx950: v_permlane32_swap / v_permlane16_swap across the halves and the
+// rows of a wave, DPP row rotation / mirrors / quad permutations inside a row) — __shfl_xor compiles to ds_bpermute_b32,
+// a round trip through the LDS pipe.  All lanes of the wave must be active.
+template <int J>
+__device__ inline u32 xor_lane(const u32 d, const int lane) {   // d of lane ^ J
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "a power of two below 64");
+    if (J == 1) return (u32)__builtin_amdgcn_update_dpp(0, (int)d, 0xB1, 0xf, 0xf, false);    // quad_perm:[1,0,3,2]
+    if (J == 2) return (u32)__builtin_amdgcn_update_dpp(0, (int)d, 0x4E, 0xf, 0xf, false);    // quad_perm:[2,3,0,1]
+    if (J == 4) {   // lane ^ 7 (row_half_mirror), then lane ^ 3 (quad_perm:[3,2,1,0])
+        const u32 t = (u32)__builtin_amdgcn_update_dpp(0, (int)d, 0x141, 0xf, 0xf, false);
+        return (u32)__builtin_amdgcn_update_dpp(0, (int)t, 0x1B, 0xf, 0xf, false);
+    }
+    if (J == 8) return (u32)__builtin_amdgcn_update_dpp(0, (int)d, 0x128, 0xf, 0xf, false);   // row_ror:8
+    if (J == 16) {   // the odd rows of the first operand change places with the even rows of the second; both are d
+        const auto r = __builtin_amdgcn_permlane16_swap(d, d, false, false);   // {[r0 r0 r2 r2], [r1 r1 r3 r3]}
+        return (lane & 16) ? r[0] : r[1];
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap(d, d, false, false);   // {[lower lower], [upper upper]}
+    return (lane & 32) ? r[0] : r[1];
+}
+// all-lanes reductions over a wave (butterfly; every lane ends with the result)
+template <class Op>
+__device__ inline u32 wave_all(u32 x, const int lane, Op op) {
+    x = op(x, xor_lane<1>(x, lane));
+    x = op(x, xor_lane<2>(x, lane));
+    x = op(x, xor_lane<4>(x, lane));
+    x = op(x, xor_lane<8>(x, lane));
+    x = op(x, xor_lane<16>(x, lane));
+    x = op(x, xor_lane<32>(x, lane));
+    return x;
+}
+__device__ inline u32 wave_all_min(const u32 x, const int lane) { return wave_all(x, lane, [](u32 a, u32 b) { return min(a, b); }); }
+__device__ inline u32 wave_all_max(const u32 x, const int lane) { return wave_all(x, lane, [](u32 a, u32 b) { return max(a, b); }); }
+__device__ inline u64 wave_all_or(const u64 x, const int lane) {
+    const u32 lo = wave_all((u32)x, lane, [](u32 a, u32 b) { return a | b; }), hi = wave_all((u32)(x >> 32), lane, [](u32 a, u32 b) { return a | b; });
+    return (u64)lo | ((u64)hi << 32);
+}
+
 // ------------------------------------------------------------------------------------
 // stage 1 kernels
 // ------------------------------------------------------------------------------------
@@ -1003,7 +1041,8 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
         if (W && lane == 0) wkey[r] = weight_of(vals[fa]);
         u32 bmin = ~0u, bmax = 0;
         for (u32 i = lane; i < c; i += 64) { const u32 b = s_idx[f0 + i] / TB; bmin = min(bmin, b); bmax = max(bmax, b); }
-        for (int o = 32; o; o >>= 1) { bmin = min(bmin, (u32)__shfl_xor(bmin, o)); bmax = max(bmax, (u32)__shfl_xor(bmax, o)); }
+        bmin = wave_all_min(bmin, (int)lane);
+        bmax = wave_all_max(bmax, (int)lane);
         if (bmax - bmin < 32) {
             tab[lane] = 0; tab[64 + lane] = 0;
             __builtin_amdgcn_wave_barrier();
@@ -1060,11 +1099,9 @@ __global__ __launch_bounds__(KG_THREADS) void k_key_groups(const V* __restrict__
                     if (l < 64) lo |= 1ull << l; else hi |= 1ull << (l - 64);
                 } else if (b >= floor_b && b != b0 && b < nxt) nxt = b;
             }
-            for (int o = 32; o; o >>= 1) {
-                lo |= __shfl_xor(lo, o);
-                hi |= __shfl_xor(hi, o);
-                nxt = min(nxt, (u32)__shfl_xor(nxt, o));
-            }
+            lo = wave_all_or(lo, (int)lane);
+            hi = wave_all_or(hi, (int)lane);
+            nxt = wave_all_min(nxt, (int)lane);
             emit(r, fa, cur, lo, hi, groups, bigs, parked, lane == 0);
             cur = nxt;
         }
