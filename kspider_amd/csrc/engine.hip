@@ -160,6 +160,7 @@ struct ksp_engine {
     std::vector<u64> h_off;
     std::vector<u32> h_blk_off;   // distinct-key offsets of the block lists (host copy)
     std::vector<u32> h_blk_max;   // per block: largest per-source k-mer count / weight sum
+    std::vector<unsigned char> act32;   // work list: some share of the active tile counts in 32 bits (the second pass of the join is launched for those only)
     // workspace
     ksp::Buf d_off, KA, KB, VA, VB, R1, FK, FT, asm_small, tmp, bkeys, info, bw, mm, blk_raw, blk_pos, blk_max, part, scalars, count, tailbuf, smap;
     u32 slots = 0;                // workgroups of k_join the chip holds at once (occupancy x CUs)
@@ -1565,6 +1566,7 @@ static int build_schedule(ksp_engine* e) {
     wg.clear();
     wg.reserve(A + (size_t)e->slots * 4);
     e->act_rec.resize(4 * (A + 1));
+    e->act32.assign(A, 0);
     u32 nsplit = 0;
     for (size_t i = 0; i < A; ++i) {
         u32 I, J;
@@ -1582,6 +1584,16 @@ static int build_schedule(ksp_engine* e) {
             u64 per_share = std::min<u64>(std::max<u64>(e->n_matches / ((u64)e->slots * 4) + 1, 8192), 1u << 20);
             if (e->h_blk_max[I] >= 65536u && e->h_blk_max[J] >= 65536u && !std::getenv("KSP_DEBUG_NO16CUT")) per_share = std::min<u64>(per_share, 65535);   // (16-bit counters: above)
             sp = std::min<u64>(std::max<u64>(((u64)(ms[i + 1] - ms[i]) + per_share - 1) / per_share, 1), 1024);
+        }
+        {   // does any share of this tile count in 32 bits?  (the rule of k_join, with the largest share of the tile)
+            u64 lim = std::min(e->h_blk_max[I], e->h_blk_max[J]);
+            if (!e->weighted) {
+                const u64 mine = (e->matches_on && I != J) ? ((u64)(ms[i + 1] - ms[i]) + sp - 1) / sp
+                               : I == J                    ? (words_of(I) + sp - 1) / sp
+                                                           : std::min(words_of(I), words_of(J));
+                lim = std::min(lim, mine);
+            }
+            e->act32[i] = lim >= 65536u;
         }
         u32* r = &e->act_rec[4 * i];
         r[0] = I; r[1] = J; r[2] = (u32)wg.size(); r[3] = nsplit;
@@ -2240,7 +2252,10 @@ int ksp_engine_join_launch(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end
         // tiles with packed 16-bit counters, then those with 32-bit counters (64 KB of LDS: two workgroups per CU).  The
         // second pass runs on a stream of its own BESIDE the first — its few fat workgroups leave most of every CU's
         // wave slots free (metagenome bins: 9.2 + 4.3 ms one after the other).
-        bool two_streams = e->need32 && !std::getenv("KSP_DEBUG_ONE_STREAM");
+        // (... and not at all when every share of the range stays below 2^16: build_schedule knows every share's bound)
+        bool pass32 = false;
+        for (size_t i = act0; e->need32 && !pass32 && i < act1; ++i) pass32 = e->act32[i] != 0;
+        bool two_streams = pass32 && !std::getenv("KSP_DEBUG_ONE_STREAM");
         if (two_streams) {
             if (!e->aux_stream && hipStreamCreateWithFlags(&e->aux_stream, hipStreamNonBlocking) != hipSuccess) two_streams = false;
             for (int i = 0; i < 2 && two_streams; ++i)
@@ -2250,7 +2265,7 @@ int ksp_engine_join_launch(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end
             KSP_HIP(hipEventRecord(e->ev_aux[0], st));                    // (the zeroing launch above)
             KSP_HIP(hipStreamWaitEvent(e->aux_stream, e->ev_aux[0], 0));
         }
-        for (int pass = 0; pass < (e->need32 ? 2 : 1); ++pass) {
+        for (int pass = 0; pass < (pass32 ? 2 : 1); ++pass) {
             hipStream_t ps = (pass == 1 && two_streams) ? e->aux_stream : st;
             for (u64 w = wgA; w < wgB; w += kMaxTilesPerLaunch) {
                 a.wg0 = (u32)w;
