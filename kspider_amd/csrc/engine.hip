@@ -352,6 +352,280 @@ static hipError_t resolve_build_ms(ksp_engine* e) {
     return hipEventElapsedTime(&e->st.ms_build, e->ev[0], e->ev[1]);
 }
 
+// What the parts of a stage-1 build share: the engine's arrays under the names its passes use (build_impl fills it in).
+template <class V>
+struct Stage1 {
+    ksp_engine* e;
+    hipStream_t st;
+    int phase;
+    u64 n;              // entries of this build
+    u32 N, nb;          // sources, blocks
+    u64* KA;
+    V *VA, *VB;
+    u64* scal;
+    u32 *blk_raw, *blk_pos, *rank1, *crank;
+    u32 *label, *iota, *labs, *order, *newidx, *sbound, *sorted_src, *blk_src;   // the per-source maps (smap)
+    int bbits;          // bits of a block id
+    bool reorder, hand_zeroed;
+    u64 m;              // kept entries
+};
+// the names of a Stage1 as locals (the bodies below were written inside build_impl)
+#define KSP_STAGE1_LOCALS(c)                                                                                             \
+    constexpr bool W = std::is_same<V, u64>::value;                                                                      \
+    ksp_engine* const e = (c).e;                                                                                         \
+    const hipStream_t st = (c).st;                                                                                       \
+    const int phase = (c).phase;                                                                                         \
+    const u64 n = (c).n, m = (c).m;                                                                                      \
+    const u32 N = (c).N, nb = (c).nb;                                                                                    \
+    const unsigned bs = 256;                                                                                             \
+    u64* const KA = (c).KA;                                                                                              \
+    V *const VA = (c).VA, *const VB = (c).VB;                                                                            \
+    u64* const scal = (c).scal;                                                                                          \
+    u32 *const blk_raw = (c).blk_raw, *const blk_pos = (c).blk_pos, *const rank1 = (c).rank1, *const crank = (c).crank;   \
+    u32 *const label = (c).label, *const iota = (c).iota, *const labs = (c).labs, *const order = (c).order;              \
+    u32 *const newidx = (c).newidx, *const sbound = (c).sbound, *const sorted_src = (c).sorted_src, *const blk_src = (c).blk_src; \
+    const int bbits = (c).bbits;                                                                                         \
+    const bool reorder = (c).reorder, hand_zeroed = (c).hand_zeroed;                                                     \
+    int rc = KSP_OK;                                                                                                     \
+    size_t tb = 0;                                                                                                       \
+    (void)W; (void)phase; (void)n; (void)m; (void)N; (void)nb; (void)bs; (void)KA; (void)VA; (void)VB; (void)scal;       \
+    (void)blk_raw; (void)blk_pos; (void)rank1; (void)crank; (void)label; (void)iota; (void)labs; (void)order;            \
+    (void)newidx; (void)sbound; (void)sorted_src; (void)blk_src; (void)bbits; (void)reorder; (void)hand_zeroed;          \
+    (void)rc; (void)tb
+
+// the sources in (label, id) order: engine index of every source, block boundaries at cluster boundaries
+template <class V>
+static int stage1_source_order(const Stage1<V>& c) {
+    KSP_STAGE1_LOCALS(c);
+    if (reorder) {
+        // order the sources by (label, id) and move the kept entries to the new indices
+        int lbits = 1;
+        while (lbits < 32 && (N >> lbits)) ++lbits;
+        tb = 0;
+        u32* sort_out = e->padded ? sorted_src : order;
+        KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, label, labs, iota, sort_out, (size_t)N, 0, lbits, st));
+        if ((rc = e->tmp.ensure(tb))) return rc;
+        KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, label, labs, iota, sort_out, (size_t)N, 0, lbits, st));
+        if (e->padded) {   // block boundaries at cluster boundaries where the spare slots allow
+            hipLaunchKernelGGL(k_pack_blocks, dim3(1), dim3(1024), 0, st, labs, N, nb, blk_src);
+            hipLaunchKernelGGL(k_place_sources, dim3(grid_for((u64)nb * TB, bs)), dim3(bs), 0, st, sorted_src, blk_src, newidx, order,
+                               sbound, e->blk_max.as<u32>(), nb);
+        } else {
+            hipLaunchKernelGGL(k_perm_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, newidx, sbound, e->blk_max.as<u32>(), N);
+        }
+    }
+    return KSP_OK;
+}
+
+// The block lists, key by key (k_key_groups ... k_ms_place / the library sort of the group records ... k_cidx).  done = false:
+// a key with thousands of holders in too many blocks — the caller takes the sort-by-block path (and the engine remembers).
+template <class V>
+static int stage1_lists_by_key(const Stage1<V>& c, bool& done) {
+    KSP_STAGE1_LOCALS(c);
+    done = false;
+    // ---- the block lists, key by key (see k_key_groups) ------------------------------------------------
+    if (!e->key_groups_off && m < (1ull << 32) - KG_CHUNK) {
+        const u32 U = (u32)e->h_scal[2];
+        const bool post_in = phase == 3 || e->post_slice;   // postings input: the key offsets are the caller's
+        const u32* firstp = post_in ? e->post_off : (const u32*)e->FK.p;   // where each key's entries start (sentinel at U)
+        u64* gsum = (u64*)KA;                 // per key: groups | masks << 32   (KA: the sorted keys are dead)
+        u64* goff = gsum + (U + 2);
+        u32* tmp_blk = (u32*)e->KB.p;         // records parked at entry positions (KB: free since the grouping by key)
+        u32* tmp_info = tmp_blk + (m + 2);
+        // gm: per key the mask, block and posting word of its first group, then the parked masks of further groups
+        if ((rc = e->gm.ensure(((size_t)U + 4) * 24 + ((size_t)m / 4 + 4) * 16 + KG_HUGE_CAP * 4))) return rc;
+        uint4* mask0 = e->gm.as<uint4>();
+        uint4* tmp_mask = mask0 + (U + 4);
+        u32 *blk0 = (u32*)(tmp_mask + (m / 4 + 4)), *info0 = blk0 + (U + 4);
+        u32* huge_list = nb <= KG_HUGE_NB ? info0 + (U + 4) : nullptr;   // keys with more than KG_MAXC holders
+        u32* wkey = W ? (u32*)VB : nullptr;   // (VB: the partitioned tags are dead)
+        u32* d_kovf = (u32*)(scal + 11);
+        const u32 chunks = (u32)((m + KG_CHUNK - 1) / KG_CHUNK);
+        phase_mark(e, st, "key groups");
+        if (!(hand_zeroed && phase == 0)) KSP_HIP(hipMemsetAsync(d_kovf, 0, 8, st));   // (the hand-written partition's build zeroes the whole scalar block at its start)
+        if (post_in) KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input only — are visited by no chunk)
+        hipLaunchKernelGGL((k_key_groups<V, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, crank, firstp, newidx, (u32)m, U,
+                           gsum, blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf,
+                           std::getenv("KSP_DEBUG_COOP") ? std::max<u32>(KG_COOP_MIN, (u32)std::atoi(std::getenv("KSP_DEBUG_COOP"))) : KG_COOP,   // (timing experiments: the wave-per-key threshold)
+                           huge_list);
+        if (huge_list)
+            hipLaunchKernelGGL((k_key_groups_huge<V, W>), dim3(256), dim3(256), 0, st, VA, firstp, newidx, nb, gsum, blk0,
+                               info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf, huge_list);
+        tb = 0;
+        KSP_HIP(rocprim::exclusive_scan(nullptr, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
+        if ((rc = e->tmp.ensure(tb))) return rc;
+        KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
+        hipLaunchKernelGGL(k_group_totals, dim3(1), dim3(64), 0, st, gsum, goff, scal, U);
+        // the number of groups sizes the sort of the groups and what follows; the records themselves are packed (k_move_groups)
+        // while the host waits for it: their arrays take the bound K <= m
+        KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 88, hipMemcpyDeviceToHost, st));   // [1] groups ... [11] overflow (one copy)
+        KSP_HIP(hipEventRecord(e->ev_rb, st));
+        const u64 Kcap = m;
+        if ((rc = e->gp.ensure((Kcap + 4) * 20))) return rc;
+        e->gp_stride = Kcap + 4;
+        u64* rec_val = e->gp.as<u64>();
+        u32 *rec_blk = (u32*)(rec_val + (Kcap + 4)), *rec_rank = rec_blk + (Kcap + 4), *sblk = rec_rank + (Kcap + 4);
+        unsigned long long* work = nullptr;
+        {
+            // (the diagonal work and holder sums of the join's schedule come with the move when the blocks fit its LDS table)
+            phase_mark(e, st, "block lists");
+            if (nb <= KG_WORK && phase != 2) {
+                if ((rc = e->dwork.ensure(((size_t)nb + 2) * 8))) return rc;
+                if (!e->pre_zeroed_work) KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
+                e->pre_zeroed_work = false;
+                work = e->dwork.as<unsigned long long>();
+            }
+            u32 mg_cap = 512u;
+            if (const char* mc = std::getenv("KSP_DEBUG_MOVE_GRID")) mg_cap = (u32)std::max(1, std::atoi(mc));   // (timing experiments)
+            hipLaunchKernelGGL(k_move_groups, dim3(std::min<u32>(grid_for(U, bs), mg_cap)), dim3(bs), 0, st, gsum, goff, firstp,
+                               blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, rec_blk, rec_val, rec_rank, e->mm.as<uint4>(),
+                               U, work, nb, d_kovf);
+        }
+        KSP_HIP(wait_readback(e));
+        if ((u32)e->h_scal[11]) {
+            e->key_groups_off = true;   // a key with thousands of holders: this engine sorts by block from now on
+        } else {
+            const u64 K = std::max<u64>(1, e->h_scal[1]);
+            u64* sval = (u64*)KA;             // (the per-key counts and offsets are dead once the records are packed)
+            e->have_dwork = work != nullptr;
+            const char* msv = std::getenv("KSP_MS");   // 0: the library sort (diagnostic / tests)
+            // (up to 256 blocks; the 1 024-block tables are slower than the library's two radix passes — C3: block lists 1.04 -> 1.38 ms
+            //  for 0.23 ms of join, C4 4.1 -> 5.3 — and only run when KSP_MS=1024 asks for them: tests)
+            const u32 ms_max = (msv && std::atoi(msv) == 1024) ? MS_MAXB : 256u;
+            if (nb <= ms_max && Kcap / MS_CHUNK < (1u << 20) && !(msv && std::atoi(msv) == 0)) {
+                // stable split of the records on the block id, written straight into the padded lists (stage1_kernels: k_ms_*)
+                const u32 mb = nb <= 256 ? 256u : 1024u;   // table size (two instantiations)
+                const u32 chunks_cap = grid_for(Kcap, MS_CHUNK), chunks = grid_for(K, MS_CHUNK);
+                if ((rc = e->ms_hist.ensure(((size_t)chunks_cap + 1) * mb * 4 + 4096))) return rc;
+                u32* hist = e->ms_hist.as<u32>();
+                u32* tot = hist + (size_t)chunks_cap * mb;
+                if (mb == 256) hipLaunchKernelGGL(k_ms_hist<256>, dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, scal, hist);
+                else hipLaunchKernelGGL(k_ms_hist<1024>, dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, scal, hist);
+                hipLaunchKernelGGL(k_ms_scan, dim3(nb), dim3(256), 0, st, hist, mb, scal, tot, blk_raw, blk_pos, nb);
+                // early work list (step_launch): everything the host needs to cut the join's shares exists now — the records in
+                // rank order (tile flags), the diagonal work, the list offsets — and leaves for pinned memory in front of the
+                // placement pass; the host works while k_ms_place and k_cidx run.  (On a stream of its own, beside the placement
+                // pass, the hand-over between the streams cost more than the four small kernels: 1.334 against 1.320 ms per step.)
+                e->sched_early = false;
+                if (e->early_ok && phase == 0 && !e->profiling && e->n_kept && !sched_wants_matches(e, K, true) && !std::getenv("KSP_DEBUG_LATE_SCHED")) {
+                    e->have_rank_pairs = true;
+                    e->h_scal_words = e->h_scal[1];
+                    e->h_scal_keys = e->h_scal[2];
+                    if ((rc = launch_sched_kernels(e, st, true))) return rc;
+                    if (!e->blk_staged && (rc = stage_block_tables(e, st))) return rc;
+                    KSP_HIP(hipEventRecord(e->ev_sched, st));
+                    e->sched_early = true;
+                }
+                uint4* pm = nullptr;
+                if (!W && m >= 4 * K) {   // unweighted lists with multi-source postings (no match records: the rule of
+                                          // launch_sched_kernels): the join's bit-sliced paths read the masks at the list positions
+                    if ((rc = e->pmask.ensure((Kcap + (u64)nb * (WIN + 4) + 4 * WIN) * 16))) return rc;
+                    pm = e->pmask.as<uint4>();
+                }
+                if (mb == 256)
+                    hipLaunchKernelGGL((k_ms_place<W, 256>), dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, rec_val, scal, hist, blk_pos, nb, wkey,
+                                       e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, e->mm.as<uint4>(), pm, blk_raw, PAD);
+                else
+                    hipLaunchKernelGGL((k_ms_place<W, 1024>), dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, rec_val, scal, hist, blk_pos, nb, wkey,
+                                       e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, e->mm.as<uint4>(), pm, blk_raw, PAD);
+                e->pmask_on = pm != nullptr;
+            } else {
+            tb = 0;   // (temporary storage for the bound, not for this build's K: K moves a little from build to build — the labels'
+                          //  atomics race — and a buffer that has to grow in the middle of a build costs a device-wide stall)
+                KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)Kcap, 0, bbits, st));
+                if ((rc = e->tmp.ensure(tb))) return rc;
+                tb = 0;
+                KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
+                KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
+                if (nb <= 1024) {   // (one workgroup while the serial layout of the starts is short: 7 813 blocks took 0.32 ms in it)
+                    hipLaunchKernelGGL(k_blk_raw_pos, dim3(1), dim3(1024), 0, st, sblk, (u32)e->h_scal[1], blk_raw, blk_pos, scal, nb);
+                } else {
+                    hipLaunchKernelGGL(k_blk_raw_groups, dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, sblk, (u32)e->h_scal[1], blk_raw, nb);
+                    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(1024), 0, st, blk_raw, blk_pos, scal, nb);
+                }
+                hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
+                hipLaunchKernelGGL((k_place_groups<W>), dim3(grid_for(K, bs)), dim3(bs), 0, st, sblk, sval, blk_raw, blk_pos, wkey,
+                                   e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, (u32)e->h_scal[1]);
+            }
+            {   // the fine cell index was sized from the raw entries of a block; the lists are an order of magnitude shorter
+                // (pruned, one word per key and block): ~32 words of an average list x 4 per cell is as fine as the join
+                // ever looks (it merges cells up to ~216 keys anyway) — 16 x fewer bisections on C2 (32 -> 4 us)
+                const u64 avg = K / nb + 1;
+                u32 nc = NP;
+                while ((u64)nc * 32 < 4 * avg && nc < e->ncell) nc <<= 1;
+                e->ncell = std::min(e->ncell, nc);
+            }
+            hipLaunchKernelGGL(k_cidx, dim3(grid_for((u64)nb * (e->ncell + 1), bs)), dim3(bs), 0, st, e->bkeys.as<u32>(),
+                               blk_raw, blk_pos, scal, e->part.as<u32>(), nb, e->ncell);
+            KSP_HIP(hipGetLastError());
+            e->scal_fresh = phase == 0;   // (h_scal[1] .. [11] are this build's: build_common need not fetch them again)
+            e->have_rank_pairs = true;   // rec_rank / rec_blk: (rank, block) of every list word in rank order
+            done = true;
+            return KSP_OK;
+        }
+    }
+    return KSP_OK;
+}
+
+// The block lists by sorting the kept entries by block (the fallback of stage1_lists_by_key, and inputs beyond its limits).
+template <class V>
+static int stage1_lists_by_sort(const Stage1<V>& c) {
+    KSP_STAGE1_LOCALS(c);
+    // ---- the block lists by sorting the entries by block -------------------------------------------------
+    if (!e->rank1_ok) {   // (the grouping wrote crank[] only: a rank per entry from first[])
+        const u32* fp = (phase == 3 || e->post_slice) ? e->post_off : (const u32*)e->FK.p;
+        hipLaunchKernelGGL(k_rank_fill, dim3(1024), dim3(256), 0, st, fp, (u32)e->h_scal[2], rank1);
+        e->rank1_ok = true;
+    }
+    if (reorder) hipLaunchKernelGGL((k_retag<V>), dim3(grid_for(m / (16 / sizeof(V)) + 1, bs)), dim3(bs), 0, st, VA, newidx, m);
+    // sort 2: stable by block id (bits [8, 8+bbits) of the tag), payload = rank:  VA,rank1 -> VB,rk2
+    u32* rk2 = (u32*)KA;                   // KA (sorted keys) is dead from here on
+    tb = 0;
+    const int bbeg = sizeof(V) == 2 ? 7 : 8;   // the block id inside a compact / canonical tag
+    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, VA, VB, rank1, rk2, m, bbeg, bbeg + bbits, st));
+    if ((rc = e->tmp.ensure(tb))) return rc;
+    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, VA, VB, rank1, rk2, m, bbeg, bbeg + bbits, st));
+    // now: rk2 = ranks sorted by (block, rank); VB = tags in the same order.  KB, VA, R1 are free.
+    V* T = VB;
+    u32* flag = (u32*)VA;
+    u32* grank = (u32*)e->KB.p;            // rank of every (block, key) group (up to m)
+    u32* estart = (u32*)e->KB.p + (n + 2); // first entry of every group (up to m+1)
+    const HeadFn<V> head{rk2, T};
+    auto hf = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u64>(0), head);
+    {
+        HeadScatterIt<V> out{{head, estart, grank, scal, m}, 0};
+        tb = 0;
+        KSP_HIP(rocprim::inclusive_scan(nullptr, tb, hf, out, m, rocprim::plus<u32>(), st));
+        if ((rc = e->tmp.ensure(tb))) return rc;
+        KSP_HIP(rocprim::inclusive_scan(e->tmp.p, tb, hf, out, m, rocprim::plus<u32>(), st));
+    }
+    // the number of distinct (block, key) groups sizes the posting passes (after the source reordering it is
+    // an order of magnitude below the entry count: one 8-byte read-back pays for itself)
+    KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 8, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL((k_blk_raw<V>), dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, T, estart, scal, blk_raw, nb, m);
+    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(1024), 0, st, blk_raw, blk_pos, scal, nb);
+    hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
+    KSP_HIP(hipStreamSynchronize(st));
+    const u64 K = std::max<u64>(1, e->h_scal[1]);
+    u32* mmsz = flag;                      // (VA is free: the head flags are computed on the fly)
+    u32* mmoff = (u32*)KA;                 // rk2 is dead after the head scan
+    hipLaunchKernelGGL((k_emit_keys<V>), dim3(grid_for(K, bs)), dim3(bs), 0, st, grank, T, estart, blk_raw, blk_pos,
+                       e->bkeys.as<u32>(), e->h_scal[1]);
+    hipLaunchKernelGGL(k_bigflag, dim3(grid_for(K, bs)), dim3(bs), 0, st, estart, scal, mmsz, K);
+    tb = 0;
+    KSP_HIP(rocprim::exclusive_scan(nullptr, tb, mmsz, mmoff, (u32)0, K, rocprim::plus<u32>(), st));
+    if ((rc = e->tmp.ensure(tb))) return rc;
+    KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, mmsz, mmoff, (u32)0, K, rocprim::plus<u32>(), st));
+    hipLaunchKernelGGL(k_nbig, dim3(1), dim3(64), 0, st, mmsz, mmoff, scal);
+    hipLaunchKernelGGL((k_emit_info<V, W>), dim3(grid_for(K, bs)), dim3(bs), 0, st, estart, mmoff, scal, T,
+                       blk_raw, blk_pos, e->info.as<u32>(), e->mm.as<uint4>(), W ? e->bw.as<u32>() : nullptr);
+    // rank-range partition of every block list
+    hipLaunchKernelGGL(k_cidx, dim3(grid_for((u64)nb * (e->ncell + 1), bs)), dim3(bs), 0, st, e->bkeys.as<u32>(),
+                       blk_raw, blk_pos, scal, e->part.as<u32>(), nb, e->ncell);
+    KSP_HIP(hipGetLastError());
+    return KSP_OK;
+}
+
 template <class V>
 static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStream_t st, const int phase) {
     constexpr bool W = std::is_same<V, u64>::value;   // weighted: 64-bit tags carry the key's weight
@@ -1049,219 +1323,17 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     }
     if (phase == 1) return KSP_OK;
     }   // phase != 2
-    if (reorder) {
-        // order the sources by (label, id) and move the kept entries to the new indices
-        int lbits = 1;
-        while (lbits < 32 && (N >> lbits)) ++lbits;
-        tb = 0;
-        u32* sort_out = e->padded ? sorted_src : order;
-        KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, label, labs, iota, sort_out, (size_t)N, 0, lbits, st));
-        if ((rc = e->tmp.ensure(tb))) return rc;
-        KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, label, labs, iota, sort_out, (size_t)N, 0, lbits, st));
-        if (e->padded) {   // block boundaries at cluster boundaries where the spare slots allow
-            hipLaunchKernelGGL(k_pack_blocks, dim3(1), dim3(1024), 0, st, labs, N, nb, blk_src);
-            hipLaunchKernelGGL(k_place_sources, dim3(grid_for((u64)nb * TB, bs)), dim3(bs), 0, st, sorted_src, blk_src, newidx, order,
-                               sbound, e->blk_max.as<u32>(), nb);
-        } else {
-            hipLaunchKernelGGL(k_perm_bound, dim3(grid_for(N, bs)), dim3(bs), 0, st, order, newidx, sbound, e->blk_max.as<u32>(), N);
-        }
-    }
+    Stage1<V> s1{e, st, phase, n, N, nb, KA, VA, VB, scal, blk_raw, blk_pos, rank1, crank, label, iota, labs, order, newidx, sbound,
+                 sorted_src, blk_src, bbits, reorder, hand_zeroed, m};
+    if (reorder && (rc = stage1_source_order(s1))) return rc;
     if (m == 0) return KSP_OK;
     e->have_rank_pairs = false;
     e->have_dwork = false;
-    // ---- the block lists, key by key (see k_key_groups) ------------------------------------------------
     if (!e->key_groups_off && m < (1ull << 32) - KG_CHUNK) {
-        const u32 U = (u32)e->h_scal[2];
-        const bool post_in = phase == 3 || e->post_slice;   // postings input: the key offsets are the caller's
-        const u32* firstp = post_in ? e->post_off : (const u32*)e->FK.p;   // where each key's entries start (sentinel at U)
-        u64* gsum = (u64*)KA;                 // per key: groups | masks << 32   (KA: the sorted keys are dead)
-        u64* goff = gsum + (U + 2);
-        u32* tmp_blk = (u32*)e->KB.p;         // records parked at entry positions (KB: free since the grouping by key)
-        u32* tmp_info = tmp_blk + (m + 2);
-        // gm: per key the mask, block and posting word of its first group, then the parked masks of further groups
-        if ((rc = e->gm.ensure(((size_t)U + 4) * 24 + ((size_t)m / 4 + 4) * 16 + KG_HUGE_CAP * 4))) return rc;
-        uint4* mask0 = e->gm.as<uint4>();
-        uint4* tmp_mask = mask0 + (U + 4);
-        u32 *blk0 = (u32*)(tmp_mask + (m / 4 + 4)), *info0 = blk0 + (U + 4);
-        u32* huge_list = nb <= KG_HUGE_NB ? info0 + (U + 4) : nullptr;   // keys with more than KG_MAXC holders
-        u32* wkey = W ? (u32*)VB : nullptr;   // (VB: the partitioned tags are dead)
-        u32* d_kovf = (u32*)(scal + 11);
-        const u32 chunks = (u32)((m + KG_CHUNK - 1) / KG_CHUNK);
-        phase_mark(e, st, "key groups");
-        if (!(hand_zeroed && phase == 0)) KSP_HIP(hipMemsetAsync(d_kovf, 0, 8, st));   // (the hand-written partition's build zeroes the whole scalar block at its start)
-        if (post_in) KSP_HIP(hipMemsetAsync(gsum, 0, ((size_t)U + 2) * 8, st));   // (keys without entries — postings input only — are visited by no chunk)
-        hipLaunchKernelGGL((k_key_groups<V, W>), dim3(chunks), dim3(KG_THREADS), 0, st, VA, crank, firstp, newidx, (u32)m, U,
-                           gsum, blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf,
-                           std::getenv("KSP_DEBUG_COOP") ? std::max<u32>(KG_COOP_MIN, (u32)std::atoi(std::getenv("KSP_DEBUG_COOP"))) : KG_COOP,   // (timing experiments: the wave-per-key threshold)
-                           huge_list);
-        if (huge_list)
-            hipLaunchKernelGGL((k_key_groups_huge<V, W>), dim3(256), dim3(256), 0, st, VA, firstp, newidx, nb, gsum, blk0,
-                               info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf, huge_list);
-        tb = 0;
-        KSP_HIP(rocprim::exclusive_scan(nullptr, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
-        if ((rc = e->tmp.ensure(tb))) return rc;
-        KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
-        hipLaunchKernelGGL(k_group_totals, dim3(1), dim3(64), 0, st, gsum, goff, scal, U);
-        // the number of groups sizes the sort of the groups and what follows; the records themselves are packed (k_move_groups)
-        // while the host waits for it: their arrays take the bound K <= m
-        KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 88, hipMemcpyDeviceToHost, st));   // [1] groups ... [11] overflow (one copy)
-        KSP_HIP(hipEventRecord(e->ev_rb, st));
-        const u64 Kcap = m;
-        if ((rc = e->gp.ensure((Kcap + 4) * 20))) return rc;
-        e->gp_stride = Kcap + 4;
-        u64* rec_val = e->gp.as<u64>();
-        u32 *rec_blk = (u32*)(rec_val + (Kcap + 4)), *rec_rank = rec_blk + (Kcap + 4), *sblk = rec_rank + (Kcap + 4);
-        unsigned long long* work = nullptr;
-        {
-            // (the diagonal work and holder sums of the join's schedule come with the move when the blocks fit its LDS table)
-            phase_mark(e, st, "block lists");
-            if (nb <= KG_WORK && phase != 2) {
-                if ((rc = e->dwork.ensure(((size_t)nb + 2) * 8))) return rc;
-                if (!e->pre_zeroed_work) KSP_HIP(hipMemsetAsync(e->dwork.p, 0, ((size_t)nb + 2) * 8, st));
-                e->pre_zeroed_work = false;
-                work = e->dwork.as<unsigned long long>();
-            }
-            u32 mg_cap = 512u;
-            if (const char* mc = std::getenv("KSP_DEBUG_MOVE_GRID")) mg_cap = (u32)std::max(1, std::atoi(mc));   // (timing experiments)
-            hipLaunchKernelGGL(k_move_groups, dim3(std::min<u32>(grid_for(U, bs), mg_cap)), dim3(bs), 0, st, gsum, goff, firstp,
-                               blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, rec_blk, rec_val, rec_rank, e->mm.as<uint4>(),
-                               U, work, nb, d_kovf);
-        }
-        KSP_HIP(wait_readback(e));
-        if ((u32)e->h_scal[11]) {
-            e->key_groups_off = true;   // a key with thousands of holders: this engine sorts by block from now on
-        } else {
-            const u64 K = std::max<u64>(1, e->h_scal[1]);
-            u64* sval = (u64*)KA;             // (the per-key counts and offsets are dead once the records are packed)
-            e->have_dwork = work != nullptr;
-            const char* msv = std::getenv("KSP_MS");   // 0: the library sort (diagnostic / tests)
-            // (up to 256 blocks; the 1 024-block tables are slower than the library's two radix passes — C3: block lists 1.04 -> 1.38 ms
-            //  for 0.23 ms of join, C4 4.1 -> 5.3 — and only run when KSP_MS=1024 asks for them: tests)
-            const u32 ms_max = (msv && std::atoi(msv) == 1024) ? MS_MAXB : 256u;
-            if (nb <= ms_max && Kcap / MS_CHUNK < (1u << 20) && !(msv && std::atoi(msv) == 0)) {
-                // stable split of the records on the block id, written straight into the padded lists (stage1_kernels: k_ms_*)
-                const u32 mb = nb <= 256 ? 256u : 1024u;   // table size (two instantiations)
-                const u32 chunks_cap = grid_for(Kcap, MS_CHUNK), chunks = grid_for(K, MS_CHUNK);
-                if ((rc = e->ms_hist.ensure(((size_t)chunks_cap + 1) * mb * 4 + 4096))) return rc;
-                u32* hist = e->ms_hist.as<u32>();
-                u32* tot = hist + (size_t)chunks_cap * mb;
-                if (mb == 256) hipLaunchKernelGGL(k_ms_hist<256>, dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, scal, hist);
-                else hipLaunchKernelGGL(k_ms_hist<1024>, dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, scal, hist);
-                hipLaunchKernelGGL(k_ms_scan, dim3(nb), dim3(256), 0, st, hist, mb, scal, tot, blk_raw, blk_pos, nb);
-                // early work list (step_launch): everything the host needs to cut the join's shares exists now — the records in
-                // rank order (tile flags), the diagonal work, the list offsets — and leaves for pinned memory in front of the
-                // placement pass; the host works while k_ms_place and k_cidx run.  (On a stream of its own, beside the placement
-                // pass, the hand-over between the streams cost more than the four small kernels: 1.334 against 1.320 ms per step.)
-                e->sched_early = false;
-                if (e->early_ok && phase == 0 && !e->profiling && e->n_kept && !sched_wants_matches(e, K, true) && !std::getenv("KSP_DEBUG_LATE_SCHED")) {
-                    e->have_rank_pairs = true;
-                    e->h_scal_words = e->h_scal[1];
-                    e->h_scal_keys = e->h_scal[2];
-                    if ((rc = launch_sched_kernels(e, st, true))) return rc;
-                    if (!e->blk_staged && (rc = stage_block_tables(e, st))) return rc;
-                    KSP_HIP(hipEventRecord(e->ev_sched, st));
-                    e->sched_early = true;
-                }
-                uint4* pm = nullptr;
-                if (!W && m >= 4 * K) {   // unweighted lists with multi-source postings (no match records: the rule of
-                                          // launch_sched_kernels): the join's bit-sliced paths read the masks at the list positions
-                    if ((rc = e->pmask.ensure((Kcap + (u64)nb * (WIN + 4) + 4 * WIN) * 16))) return rc;
-                    pm = e->pmask.as<uint4>();
-                }
-                if (mb == 256)
-                    hipLaunchKernelGGL((k_ms_place<W, 256>), dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, rec_val, scal, hist, blk_pos, nb, wkey,
-                                       e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, e->mm.as<uint4>(), pm, blk_raw, PAD);
-                else
-                    hipLaunchKernelGGL((k_ms_place<W, 1024>), dim3(chunks), dim3(MS_THREADS), 0, st, rec_blk, rec_val, scal, hist, blk_pos, nb, wkey,
-                                       e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, e->mm.as<uint4>(), pm, blk_raw, PAD);
-                e->pmask_on = pm != nullptr;
-            } else {
-            tb = 0;   // (temporary storage for the bound, not for this build's K: K moves a little from build to build — the labels'
-                          //  atomics race — and a buffer that has to grow in the middle of a build costs a device-wide stall)
-                KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)Kcap, 0, bbits, st));
-                if ((rc = e->tmp.ensure(tb))) return rc;
-                tb = 0;
-                KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
-                KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, rec_blk, sblk, rec_val, sval, (size_t)K, 0, bbits, st));
-                if (nb <= 1024) {   // (one workgroup while the serial layout of the starts is short: 7 813 blocks took 0.32 ms in it)
-                    hipLaunchKernelGGL(k_blk_raw_pos, dim3(1), dim3(1024), 0, st, sblk, (u32)e->h_scal[1], blk_raw, blk_pos, scal, nb);
-                } else {
-                    hipLaunchKernelGGL(k_blk_raw_groups, dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, sblk, (u32)e->h_scal[1], blk_raw, nb);
-                    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(1024), 0, st, blk_raw, blk_pos, scal, nb);
-                }
-                hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
-                hipLaunchKernelGGL((k_place_groups<W>), dim3(grid_for(K, bs)), dim3(bs), 0, st, sblk, sval, blk_raw, blk_pos, wkey,
-                                   e->bkeys.as<u32>(), e->info.as<u32>(), W ? e->bw.as<u32>() : nullptr, (u32)e->h_scal[1]);
-            }
-            {   // the fine cell index was sized from the raw entries of a block; the lists are an order of magnitude shorter
-                // (pruned, one word per key and block): ~32 words of an average list x 4 per cell is as fine as the join
-                // ever looks (it merges cells up to ~216 keys anyway) — 16 x fewer bisections on C2 (32 -> 4 us)
-                const u64 avg = K / nb + 1;
-                u32 nc = NP;
-                while ((u64)nc * 32 < 4 * avg && nc < e->ncell) nc <<= 1;
-                e->ncell = std::min(e->ncell, nc);
-            }
-            hipLaunchKernelGGL(k_cidx, dim3(grid_for((u64)nb * (e->ncell + 1), bs)), dim3(bs), 0, st, e->bkeys.as<u32>(),
-                               blk_raw, blk_pos, scal, e->part.as<u32>(), nb, e->ncell);
-            KSP_HIP(hipGetLastError());
-            e->scal_fresh = phase == 0;   // (h_scal[1] .. [11] are this build's: build_common need not fetch them again)
-            e->have_rank_pairs = true;   // rec_rank / rec_blk: (rank, block) of every list word in rank order
-            return KSP_OK;
-        }
+        bool done = false;
+        if ((rc = stage1_lists_by_key(s1, done)) || done) return rc;
     }
-    // ---- the block lists by sorting the entries by block -------------------------------------------------
-    if (!e->rank1_ok) {   // (the grouping wrote crank[] only: a rank per entry from first[])
-        const u32* fp = (phase == 3 || e->post_slice) ? e->post_off : (const u32*)e->FK.p;
-        hipLaunchKernelGGL(k_rank_fill, dim3(1024), dim3(256), 0, st, fp, (u32)e->h_scal[2], rank1);
-        e->rank1_ok = true;
-    }
-    if (reorder) hipLaunchKernelGGL((k_retag<V>), dim3(grid_for(m / (16 / sizeof(V)) + 1, bs)), dim3(bs), 0, st, VA, newidx, m);
-    // sort 2: stable by block id (bits [8, 8+bbits) of the tag), payload = rank:  VA,rank1 -> VB,rk2
-    u32* rk2 = (u32*)KA;                   // KA (sorted keys) is dead from here on
-    tb = 0;
-    const int bbeg = sizeof(V) == 2 ? 7 : 8;   // the block id inside a compact / canonical tag
-    KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, VA, VB, rank1, rk2, m, bbeg, bbeg + bbits, st));
-    if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, VA, VB, rank1, rk2, m, bbeg, bbeg + bbits, st));
-    // now: rk2 = ranks sorted by (block, rank); VB = tags in the same order.  KB, VA, R1 are free.
-    V* T = VB;
-    u32* flag = (u32*)VA;
-    u32* grank = (u32*)e->KB.p;            // rank of every (block, key) group (up to m)
-    u32* estart = (u32*)e->KB.p + (n + 2); // first entry of every group (up to m+1)
-    const HeadFn<V> head{rk2, T};
-    auto hf = rocprim::make_transform_iterator(rocprim::make_counting_iterator<u64>(0), head);
-    {
-        HeadScatterIt<V> out{{head, estart, grank, scal, m}, 0};
-        tb = 0;
-        KSP_HIP(rocprim::inclusive_scan(nullptr, tb, hf, out, m, rocprim::plus<u32>(), st));
-        if ((rc = e->tmp.ensure(tb))) return rc;
-        KSP_HIP(rocprim::inclusive_scan(e->tmp.p, tb, hf, out, m, rocprim::plus<u32>(), st));
-    }
-    // the number of distinct (block, key) groups sizes the posting passes (after the source reordering it is
-    // an order of magnitude below the entry count: one 8-byte read-back pays for itself)
-    KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 8, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL((k_blk_raw<V>), dim3(grid_for((u64)nb + 1, bs)), dim3(bs), 0, st, T, estart, scal, blk_raw, nb, m);
-    hipLaunchKernelGGL(k_blk_pos, dim3(1), dim3(1024), 0, st, blk_raw, blk_pos, scal, nb);
-    hipLaunchKernelGGL(k_pad, dim3(nb + 1), dim3(256), 0, st, blk_raw, blk_pos, e->bkeys.as<u32>(), nb, PAD);
-    KSP_HIP(hipStreamSynchronize(st));
-    const u64 K = std::max<u64>(1, e->h_scal[1]);
-    u32* mmsz = flag;                      // (VA is free: the head flags are computed on the fly)
-    u32* mmoff = (u32*)KA;                 // rk2 is dead after the head scan
-    hipLaunchKernelGGL((k_emit_keys<V>), dim3(grid_for(K, bs)), dim3(bs), 0, st, grank, T, estart, blk_raw, blk_pos,
-                       e->bkeys.as<u32>(), e->h_scal[1]);
-    hipLaunchKernelGGL(k_bigflag, dim3(grid_for(K, bs)), dim3(bs), 0, st, estart, scal, mmsz, K);
-    tb = 0;
-    KSP_HIP(rocprim::exclusive_scan(nullptr, tb, mmsz, mmoff, (u32)0, K, rocprim::plus<u32>(), st));
-    if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, mmsz, mmoff, (u32)0, K, rocprim::plus<u32>(), st));
-    hipLaunchKernelGGL(k_nbig, dim3(1), dim3(64), 0, st, mmsz, mmoff, scal);
-    hipLaunchKernelGGL((k_emit_info<V, W>), dim3(grid_for(K, bs)), dim3(bs), 0, st, estart, mmoff, scal, T,
-                       blk_raw, blk_pos, e->info.as<u32>(), e->mm.as<uint4>(), W ? e->bw.as<u32>() : nullptr);
-    // rank-range partition of every block list
-    hipLaunchKernelGGL(k_cidx, dim3(grid_for((u64)nb * (e->ncell + 1), bs)), dim3(bs), 0, st, e->bkeys.as<u32>(),
-                       blk_raw, blk_pos, scal, e->part.as<u32>(), nb, e->ncell);
-    KSP_HIP(hipGetLastError());
-    return KSP_OK;
+    return stage1_lists_by_sort(s1);
 }
 
 // tag type of a build: 64-bit (weighted), compact 16-bit (unweighted, <= 65536 sources) or canonical 32-bit
