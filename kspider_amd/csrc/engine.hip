@@ -285,6 +285,7 @@ static u32 label_sampling(const ksp_engine* e, u64 kept_entries) {
     }
     u32 every = 1;
     while (every < 64 && small / (2 * every) >= 64) every *= 2;
+    if (const char* ev = std::getenv("KSP_DEBUG_LABEL_EVERY")) every = (u32)std::max(1, std::atoi(ev));   // (timing experiments)
     return every - 1;
 }
 
