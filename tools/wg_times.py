@@ -55,3 +55,38 @@ for kind, sel in (("diag", I == J), ("off", I != J)):
 order = np.argsort(-dur)[:12]
 for i in order:
     print(f"  wg {i:6d} tile ({I[i]},{J[i]}) sp {sp[i]:3d}: start {us(t0[i] - base):7.1f} dur {dur[i]:7.1f} us  phases " + " ".join(f"{x:.0f}" for x in ph[i]))
+
+# ---- what the host's cost model sees against what the shares take (WG_FIT=1): per tile, time x shares vs list lengths ----
+if os.environ.get("WG_FIT"):
+    import ctypes
+    L = engine.lib()
+    nbk = int(e.stats()["n_blocks"])
+    arr = np.zeros(nbk + 1, dtype=np.uint32)
+    L.ksp_engine_block_key_counts.restype = ctypes.c_int
+    L.ksp_engine_block_key_counts.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.ksp_engine_block_key_counts(e._h, arr.ctypes.data_as(ctypes.c_void_p))
+    off = arr.astype(np.int64)
+    w = np.diff(off)
+    rows = {}
+    for i in range(len(r)):
+        rows.setdefault((int(I[i]), int(J[i])), []).append(dur[i])
+    xs_d, ys_d, xs_o, ys_o = [], [], [], []
+    for (a, b), ds in rows.items():
+        tot, mx = float(np.sum(ds)), float(np.max(ds))
+        if a == b:
+            xs_d.append(w[a]); ys_d.append(tot)
+        else:
+            xs_o.append(w[a] + w[b]); ys_o.append(tot)
+    for name, xs, ys in (("diag: sum of share us vs words", xs_d, ys_d), ("off: sum of share us vs words(I) + words(J)", xs_o, ys_o)):
+        xs, ys = np.asarray(xs, dtype=np.float64), np.asarray(ys, dtype=np.float64)
+        A = np.vstack([xs, np.ones_like(xs)]).T
+        k, c0 = np.linalg.lstsq(A, ys, rcond=None)[0]
+        res = ys - (k * xs + c0)
+        print(f"{name}: n={len(xs)} fit us = {k * 1000:.3f} per 1000 words + {c0:.1f}; residual sd {res.std():.1f} us, max {res.max():.1f}, min {res.min():.1f}; words min {xs.min():.0f} max {xs.max():.0f}")
+    # the worst under-estimated tiles
+    pred = {}
+    for (a, b), ds in rows.items():
+        pred[(a, b)] = (float(np.sum(ds)), len(ds), int(w[a]), int(w[b]))
+    worst = sorted(pred.items(), key=lambda kv: -kv[1][0] / kv[1][1])[:15]
+    for (a, b), (tot, nsh, wa, wb) in worst:
+        print(f"  tile ({a},{b}) shares {nsh} sum {tot:.0f} us = {tot / nsh:.0f} per share; words {wa} / {wb}")
