@@ -77,6 +77,30 @@ if os.environ.get("WG_FIT"):
             xs_d.append(w[a]); ys_d.append(tot)
         else:
             xs_o.append(w[a] + w[b]); ys_o.append(tot)
+    # matches per off-diagonal tile (keys both blocks hold), from the sketches and the engine's source order — what the
+    # host's cost model does not see
+    order = e.source_order(sk.n_sources).astype(np.int64)
+    blk_of = order // 128
+    src = np.repeat(np.arange(sk.n_sources, dtype=np.int64), np.diff(sk.offsets.astype(np.int64)))
+    comb = np.unique((sk.keys.astype(np.uint64) << np.uint64(7)) | blk_of[src].astype(np.uint64))   # (key, block) pairs; C2: 100 blocks, keys < 2^55
+    kk, bb = comb >> np.uint64(7), (comb & np.uint64(127)).astype(np.int64)
+    match = {}
+    nbk2 = int(bb.max()) + 1
+    cnt2 = np.zeros(nbk2 * nbk2, dtype=np.int64)
+    for d in range(1, 64):
+        same = kk[d:] == kk[:-d]
+        if not same.any():
+            break
+        cnt2 += np.bincount(bb[:-d][same] * nbk2 + bb[d:][same], minlength=nbk2 * nbk2)
+    xs2, ys2 = [], []
+    for (a, b), ds in rows.items():
+        if a != b:
+            xs2.append((w[a] + w[b], cnt2[a * nbk2 + b])); ys2.append(float(np.sum(ds)))
+    X = np.asarray(xs2, dtype=np.float64); Y = np.asarray(ys2)
+    A2 = np.vstack([X[:, 0], X[:, 1], np.ones(len(X))]).T
+    co = np.linalg.lstsq(A2, Y, rcond=None)[0]
+    res2 = Y - A2 @ co
+    print(f"off: us = {co[0] * 1000:.3f} per 1000 words + {co[1] * 1000:.3f} per 1000 matches + {co[2]:.1f}; residual sd {res2.std():.1f} us (max {res2.max():.1f}, min {res2.min():.1f}); matches per tile min {X[:, 1].min():.0f} median {np.median(X[:, 1]):.0f} max {X[:, 1].max():.0f}")
     for name, xs, ys in (("diag: sum of share us vs words", xs_d, ys_d), ("off: sum of share us vs words(I) + words(J)", xs_o, ys_o)):
         xs, ys = np.asarray(xs, dtype=np.float64), np.asarray(ys, dtype=np.float64)
         A = np.vstack([xs, np.ones_like(xs)]).T
