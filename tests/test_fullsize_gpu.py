@@ -186,3 +186,34 @@ def test_pipelined_join_reports_overflow_at_the_wait_and_step_launch_collects_it
     n1 = eng.join_wait()
     assert a[0] == 0 and a[1] == b[0] and b[1] == T and n0 + n1 == n
     eng.close()
+
+
+@pytest.mark.parametrize("late", [False, True])
+def test_step_launch_with_the_early_work_list_gives_the_reference_edges(oracle_lib, monkeypatch, late):
+    """ksp_engine_step_launch copies the work list's inputs out in FRONT of the last two kernels of the build and cuts the
+    join's shares while those run (KSP_DEBUG_LATE_SCHED=1: at the end of the build, as every other entry point).  Both give
+    the restated reference's edge set, step after step on one engine, and the build time is there when the stats are read."""
+    if late:
+        monkeypatch.setenv("KSP_DEBUG_LATE_SCHED", "1")
+    sk = synth.generate("C2", n_sources=1200, mean_size=900, cluster_cap=40, seed=91)
+    ref = oracle_lib.brute_pairs(sk.keys, sk.offsets)
+    keys_d = engine.DeviceBuffer.from_numpy(sk.keys)
+    eng = engine.Engine(0)
+    eng.build_blocks(keys_d.ptr.value, sk.offsets)
+    cap = 2 * int(eng.edge_bound(0, eng.num_tiles)) + 1   # (the bound moves a little from build to build: the blocks do)
+    bufs = [engine.DeviceBuffer(cap * 16), engine.DeviceBuffer(cap * 16)]
+    counts = []
+    for step in range(4):   # (the join of step k is collected by the call of step k + 1)
+        t0, t1, bound, launched, prev = eng.step_launch(keys_d.ptr.value, sk.offsets, 0, 1, bufs[step & 1].ptr.value, cap)
+        assert launched and (t0, t1) == (0, eng.num_tiles)
+        st = eng.stats()
+        assert st["ms_build"] > 0 and st["n_active_tiles"] > 0, st
+        if prev is not None:
+            counts.append(prev)
+            got = np.sort(bufs[(step - 1) & 1].to_numpy(engine.EDGE_DTYPE, prev), order=["source_1", "source_2"])
+            assert len(got) == len(ref) and (got == ref).all()
+    n = eng.join_wait()
+    got = np.sort(bufs[3 & 1].to_numpy(engine.EDGE_DTYPE, n), order=["source_1", "source_2"])
+    assert len(got) == len(ref) and (got == ref).all()
+    assert counts == [len(ref)] * 3
+    eng.close()
