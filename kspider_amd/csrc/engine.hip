@@ -452,11 +452,12 @@ static int stage1_lists_by_key(const Stage1<V>& c, bool& done) {
         if (huge_list)
             hipLaunchKernelGGL((k_key_groups_huge<V, W>), dim3(256), dim3(256), 0, st, VA, firstp, newidx, nb, gsum, blk0,
                                info0, mask0, tmp_blk, tmp_info, tmp_mask, wkey, d_kovf, huge_list);
-        tb = 0;
-        KSP_HIP(rocprim::exclusive_scan(nullptr, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
-        if ((rc = e->tmp.ensure(tb))) return rc;
-        KSP_HIP(rocprim::exclusive_scan(e->tmp.p, tb, gsum, goff, (u64)0, (size_t)U, rocprim::plus<u64>(), st));
-        hipLaunchKernelGGL(k_group_totals, dim3(1), dim3(64), 0, st, gsum, goff, scal, U);
+        {   // goff = exclusive prefix sums of gsum, the totals to scal[1] / scal[7] (stage1_kernels: k_pair_*)
+            const u32 ntiles = grid_for(U, PS_TILE);
+            if ((rc = e->tmp.ensure(((size_t)ntiles + 2) * 8))) return rc;
+            hipLaunchKernelGGL(k_pair_tile_sums, dim3(ntiles), dim3(PS_THREADS), 0, st, gsum, U, (u64*)e->tmp.p);
+            hipLaunchKernelGGL(k_pair_scan_tiles, dim3(ntiles), dim3(PS_THREADS), 0, st, gsum, goff, U, (const u64*)e->tmp.p, scal);
+        }
         // the number of groups sizes the sort of the groups and what follows; the records themselves are packed (k_move_groups)
         // while the host waits for it: their arrays take the bound K <= m
         KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 88, hipMemcpyDeviceToHost, st));   // [1] groups ... [11] overflow (one copy)
