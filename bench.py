@@ -538,6 +538,8 @@ def main():
                     acc[name] = acc.get(name, 0.0) + ms
                 joins += eng.stats()["ms_join"]
             eng.set_profiling(False)
+            if ms_part == 0.0 and "partition" in acc:   # (the timed steps carry no events around the partition: an event record is a
+                ms_part = acc["partition"] / args.profile_steps   #  ~6 us bubble in the stream; the phase pass has them)
             kept = None
             # bytes each group has to move per step; None where no simple model applies
             kind = stats.get("partition_kind")

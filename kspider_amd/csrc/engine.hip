@@ -172,7 +172,7 @@ struct ksp_engine {
     bool have_bits = false;       // tbits / dwork hold this build's tile bitmap and diagonal work
     std::vector<u64> act_tid;     // active tiles (row-major tile ids, ascending)
     std::vector<u32> act_rec;     // per active tile: I, J, first workgroup, split index (+ one sentinel record)
-    ksp::Buf tbits, dwork, d_act, d_wg;
+    ksp::Buf tbits, dwork, d_act, d_wg, ticket;   // (ticket: the arrival counter of k_pack_flags_out's workgroups)
     // match-list join (inputs whose list words have few holders): records sorted by tile, first record per active tile
     ksp::Buf mcnt, moff, mt0, mt1, mr0, mr1, mstart;
     bool matches_on = false;      // mt1 / mr1 hold this build's records
@@ -196,6 +196,7 @@ struct ksp_engine {
     int part_fail = 0;                       // overflow word of the hand-written partition when it gave up (stats)
     u64 h_scal_words = 0, h_scal_keys = 0;   // list words / distinct shared keys of the lists being finished
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // build, join, first radix sort
+    bool time_sort = true;        // events around the partition / first sort (st.ms_sort): an event record is a ~6 us bubble in the stream
     hipEvent_t ev_join_done = nullptr;   // behind the count copy of the last ksp_engine_join_launch
     // early work list (ksp_engine_step_launch): the tile flags and block tables leave for the host BEHIND the histogram of
     // the stable split and IN FRONT of its placement pass — the host cuts the join's shares while k_ms_place / k_cidx run,
@@ -204,7 +205,15 @@ struct ksp_engine {
     bool early_ok = false;        // the caller queues the join itself right after the build (step_launch)
     bool sched_early = false;     // this build did it
     bool build_ms_pending = false;   // st.ms_build is read off ev[0] / ev[1] once the build's last kernel has ended
+    bool sched_signalled = false;    // the early copy-out signals through a sequence number in pinned memory (h_count[7]), not ev_sched
+    unsigned long long sched_seq = 0;
+    bool ticket_zeroed = false;
     hipEvent_t ev_rb = nullptr;          // behind a read-back the host waits for while later kernels are already queued
+    // ... or no event at all: the words go to pinned memory by a kernel of ours (k_readback) and a sequence number follows
+    // them; the host polls the number (h_scal[15]).  An event record is a ~6 us bubble in the stream.
+    unsigned long long rb_seq = 0;       // sequence number of the last k_readback
+    bool rb_flag = false;                // the pending read-back signals through the number, not through ev_rb
+    hipStream_t rb_stream = nullptr;
     double kept_frac = 0.7;              // kept / all entries of the previous build (label sampling before the count is known)
     double piece_ratio = 0;              // ksp_engine_join_to_host: densest found / bound ratio of the engine's previous call (first piece's size)
     ksp::Buf stage[2];                   // ksp_engine_join_to_host: the edges of a piece wait here for their copy
@@ -228,6 +237,18 @@ static inline unsigned grid_for(u64 n, unsigned bs) { return (unsigned)((n + bs 
 
 // wait for the read-back behind which e->ev_rb was recorded (later kernels may already be queued on the stream)
 static inline hipError_t wait_readback(ksp_engine* e) {
+    if (e->rb_flag) {
+        e->rb_flag = false;
+        volatile unsigned long long* f = reinterpret_cast<volatile unsigned long long*>(e->h_scal + 15);
+        for (unsigned long long spins = 1; *f != e->rb_seq; ++spins) {
+            if ((spins & 0xFFFFF) == 0) {   // (now and then: is the stream still alive?)
+                const hipError_t q = hipStreamQuery(e->rb_stream);
+                if (q == hipSuccess) return *f == e->rb_seq ? hipSuccess : hipErrorUnknown;   // (idle, and the number never came)
+                if (q != hipErrorNotReady) return q;
+            }
+        }
+        return hipSuccess;
+    }
     static const int mode = [] { const char* m = std::getenv("KSP_DEBUG_RBWAIT"); return m ? std::atoi(m) : 0; }();
     if (mode == 1) return hipEventSynchronize(e->ev_rb);
     hipError_t err;
@@ -312,14 +333,40 @@ __global__ void k_copy_regions(const CopyList c) {
     for (int r = 0; r < c.n; ++r)
         for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < c.words[r]; i += gridDim.x * blockDim.x) c.dst[r][i] = c.src[r][i];
 }
+// a few words of the scalar block to pinned host memory, a sequence number behind them (the host polls it: wait_readback)
+__global__ void k_readback(const u64* __restrict__ src, u64* __restrict__ dst_host, const u32 words,
+                           unsigned long long* __restrict__ flag_host, const unsigned long long seq) {
+    if (threadIdx.x < words) __hip_atomic_store(dst_host + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static inline void launch_readback(ksp_engine* e, hipStream_t st, const u64* src, u64* dst_host, const u32 words) {
+    e->rb_seq += 1;
+    e->rb_flag = true;
+    e->rb_stream = st;
+    hipLaunchKernelGGL(k_readback, dim3(1), dim3(64), 0, st, src, dst_host, words, reinterpret_cast<unsigned long long*>(e->h_scal + 15), e->rb_seq);
+}
 // the tile flags packed straight into pinned host memory, and a few small regions copied out by the same launch (the
 // work list's inputs leave the device in one dispatch instead of three: k_pack_flags, two k_copy_regions)
-__global__ void k_pack_flags_out(const unsigned char* __restrict__ flags, const u64 n, u32* __restrict__ bits_out, const CopyList c) {
+// ticket / flag_host / seq (ticket != nullptr): the workgroup that finishes last writes the sequence number behind everybody's
+// words — the host polls it instead of an event (ticket: zero at launch, left at zero).
+__global__ void k_pack_flags_out(const unsigned char* __restrict__ flags, const u64 n, u32* __restrict__ bits_out, const CopyList c,
+                                 u32* __restrict__ ticket, unsigned long long* __restrict__ flag_host, const unsigned long long seq) {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;   // blockDim is a multiple of 64
     const unsigned long long m = __ballot(t < n && flags[t] != 0);
     if ((threadIdx.x & 63) == 0 && t < n) { bits_out[t >> 5] = (u32)m; bits_out[(t >> 5) + 1] = (u32)(m >> 32); }
     for (int r = 0; r < c.n; ++r)
         for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < c.words[r]; i += gridDim.x * blockDim.x) c.dst[r][i] = c.src[r][i];
+    if (ticket) {
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            __threadfence_system();
+            *ticket = 0;
+            __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 static inline void copy_add(CopyList& c, const void* src, void* dst, size_t bytes) {
     if (!bytes) return;
@@ -335,7 +382,7 @@ static inline void zero_add(ZeroList& z, void* p, size_t bytes) {
     ++z.n;
 }
 
-static int launch_sched_kernels(ksp_engine* e, hipStream_t st, bool with_tables = false);
+static int launch_sched_kernels(ksp_engine* e, hipStream_t st, bool with_tables = false, bool signal = false);
 static int stage_block_tables(ksp_engine* e, hipStream_t st);
 // match records for the join (launch_sched_kernels): sparse sharing — few holders per list word
 static bool sched_wants_matches(const ksp_engine* e, const u64 K, const bool ranked) {
@@ -460,8 +507,7 @@ static int stage1_lists_by_key(const Stage1<V>& c, bool& done) {
         }
         // the number of groups sizes the sort of the groups and what follows; the records themselves are packed (k_move_groups)
         // while the host waits for it: their arrays take the bound K <= m
-        KSP_HIP(hipMemcpyAsync(e->h_scal + 1, scal + 1, 88, hipMemcpyDeviceToHost, st));   // [1] groups ... [11] overflow (one copy)
-        KSP_HIP(hipEventRecord(e->ev_rb, st));
+        launch_readback(e, st, scal + 1, e->h_scal + 1, 11);   // [1] groups ... [11] overflow
         const u64 Kcap = m;
         if ((rc = e->gp.ensure((Kcap + 4) * 20))) return rc;
         e->gp_stride = Kcap + 4;
@@ -513,9 +559,9 @@ static int stage1_lists_by_key(const Stage1<V>& c, bool& done) {
                     e->have_rank_pairs = true;
                     e->h_scal_words = e->h_scal[1];
                     e->h_scal_keys = e->h_scal[2];
-                    if ((rc = launch_sched_kernels(e, st, true))) return rc;
+                    if ((rc = launch_sched_kernels(e, st, true, true))) return rc;
                     if (!e->blk_staged && (rc = stage_block_tables(e, st))) return rc;
-                    KSP_HIP(hipEventRecord(e->ev_sched, st));
+                    if (!(e->sched_signalled && e->blk_staged)) { e->sched_signalled = false; KSP_HIP(hipEventRecord(e->ev_sched, st)); }   // (else: the last workgroup of the copy-out writes a sequence number the host polls)
                     e->sched_early = true;
                 }
                 uint4* pm = nullptr;
@@ -697,6 +743,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     while ((1u << bbits) < nb) ++bbits;
     size_t tb = 0;
     u64 m = e->n_kept;   // (phase 2: set by phase 1)
+    bool order_queued = false;   // the source order (label sort, block cuts, placement) was queued together with the label pass
     if (phase == 3 || phase == 4) {   // (4: a slice of a postings input — stops at the labels, ksp_engine_slice_finish runs phase 2)
         m = n;
         e->n_kept = m;
@@ -912,6 +959,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     e->n_kept = 0;
     m = 0;
     bool labels_queued = false;   // the label pass was queued before the grouping's counts were read back
+    order_queued = false;
     if (nw == 0) return KSP_OK;   // (slice mode only) no key of this range: labels stay the identity
     // sort 1: all entries by the top 32 significant key bits (payload = tag [+weight]):
     // d_keys,VA -> KA,VB; then order the rare mixed runs by the full key (k_fix_runs)
@@ -991,14 +1039,14 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             if ((rc = seg_tables(seg_nb1))) return rc;
             const u32 ngroups_s = (u32)e->seg_groups.size() - 1;
             phase_mark(e, st, "partition");
-            KSP_HIP(hipEventRecord(e->ev[4], st));
+            if (e->time_sort) KSP_HIP(hipEventRecord(e->ev[4], st));
             u64* kmin = (u64*)((char*)e->seg_grp.p + (((e->seg_groups.size() * 4) + 15) & ~(size_t)15));   // (behind the groups)
             hipLaunchKernelGGL(k_seg_prep, dim3(1), dim3(256), 0, st, scal, nbuckets, seg_pb2, seg_nb1, kmin);   // (the multiplier of this build, the ranges' first keys)
             hipLaunchKernelGGL(k_seg_bounds, dim3((u32)e->seg_chunks.size()), dim3(64 * SEG_BW), 0, st, d_keys, e->seg_chk.as<uint4>(), scal, kmin,
                                seg_pb2, nbuckets - 1, seg_nb1, e->seg_tbl.as<u32>());
             hipLaunchKernelGGL((k_seg_scatter<V>), dim3(ngroups_s * seg_nb1), dim3(P2_THREADS), 0, st, d_keys, d_off, e->seg_tbl.as<u32>(),
                                e->seg_grp.as<u32>(), scal, seg_pb2, nbuckets - 1, seg_nb1, seg_cap, hp_gcnt, KA, VB);
-            KSP_HIP(hipEventRecord(e->ev[5], st));
+            if (e->time_sort) KSP_HIP(hipEventRecord(e->ev[5], st));
             phase_mark(e, st, "bucket grouping");
             bb = BucketBounds{nullptr, hp_gcnt, seg_cap};
         } else if (hand) {
@@ -1022,7 +1070,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                 if ((rc = e->PD2.ensure(hp_pages_m * P1_PAGE))) return rc;
             }
             phase_mark(e, st, "partition");
-            KSP_HIP(hipEventRecord(e->ev[4], st));
+            if (e->time_sort) KSP_HIP(hipEventRecord(e->ev[4], st));
             if (seg3) {
                 u64* kmin = (u64*)((char*)e->seg_grp.p + (((e->seg_groups.size() * 4) + 15) & ~(size_t)15));
                 hipLaunchKernelGGL(k_seg_prep, dim3(1), dim3(256), 0, st, scal, nbuckets, hp_pb2 + hp_pbm, hp_nb1, kmin);
@@ -1059,15 +1107,15 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
             hipLaunchKernelGGL(k_scan2, dim3(hp_ngroups), dim3(256), 0, st, hp_gbase, hp_pb2, nbuckets, hp_ngroups, hp_gcnt, bstart);
             hipLaunchKernelGGL((k_scatter2<V>), dim3((u32)pages_last), dim3(P2_THREADS), 0, st, scal, last, hp_pb2, nbuckets - 1, Kl, Tl,
                                hp_gcnt, KA, VB);
-            KSP_HIP(hipEventRecord(e->ev[5], st));
+            if (e->time_sort) KSP_HIP(hipEventRecord(e->ev[5], st));
             phase_mark(e, st, "bucket grouping");   // (bsum: zeroed with the rest at the start of the build)
         } else {
         phase_mark(e, st, "partition");
         KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, KA, tags_in, VB, nw, shiftb, topbit, st));
         if ((rc = e->tmp.ensure(tb))) return rc;
-        KSP_HIP(hipEventRecord(e->ev[4], st));
+        if (e->time_sort) KSP_HIP(hipEventRecord(e->ev[4], st));
         KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, keys_in, KA, tags_in, VB, nw, shiftb, topbit, st));
-        KSP_HIP(hipEventRecord(e->ev[5], st));
+        if (e->time_sort) KSP_HIP(hipEventRecord(e->ev[5], st));
         phase_mark(e, st, "bucket grouping");
         KSP_HIP(hipMemsetAsync(d_hovf, 0, 8, st));
         KSP_HIP(hipMemsetAsync(bsum, 0, (size_t)nbuckets * 8, st));
@@ -1243,15 +1291,21 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
                            bbase, bsum, nbuckets, VA, rank_out, first, scal, crank);
         hipLaunchKernelGGL((k_bucket_big<V, 1>), dim3(1024), dim3(HB_THREADS), 0, st, KA, VB, bb, big_list, d_hovf,
                            bsum, bbase, VA, rank_out, first, crank);
-        KSP_HIP(hipMemcpyAsync(e->h_scal, scal, 120, hipMemcpyDeviceToHost, st));   // [0] max key, [2] keys, [6] entries, [9] / [14] overflow (one copy)
-        // the kept-entry count sizes every later pass — but the label pass can be queued without it (its key count
-        // comes from the device, its sampling rate from the kept fraction of the engine's previous build), so the
-        // device works on while the host waits for the copy above
+        // [0] max key, [2] keys, [6] entries, [9] / [14] overflow.  The kept-entry count sizes every later pass — but the label
+        // pass can be queued without it (its key count comes from the device, its sampling rate from the kept fraction of
+        // the engine's previous build), so the device works on while the host waits for the words
+        if (reorder) launch_readback(e, st, scal, e->h_scal, 15);
+        else KSP_HIP(hipMemcpyAsync(e->h_scal, scal, 120, hipMemcpyDeviceToHost, st));
         if (reorder) {
-            KSP_HIP(hipEventRecord(e->ev_rb, st));
             phase_mark(e, st, "source labels + order");
             run_label(first, (u32)std::min<u64>(nw / 2 + 1, 0x7FFFFFFFu), (u64)((double)nw * e->kept_frac), scal);
             labels_queued = true;
+            if (phase == 0) {   // (... and neither does the order of the sources need it: sort, block cuts and placement are queued too)
+                const Stage1<V> so{e, st, phase, n, N, nb, KA, VA, VB, scal, blk_raw, blk_pos, rank1, crank, label, iota, labs, order, newidx,
+                                   sbound, sorted_src, blk_src, bbits, reorder, hand_zeroed, 0};
+                if ((rc = stage1_source_order(so))) return rc;
+                order_queued = true;
+            }
             KSP_HIP(wait_readback(e));
         } else {
             KSP_HIP(hipStreamSynchronize(st));
@@ -1280,9 +1334,9 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     } else {
     KSP_HIP(rocprim::radix_sort_pairs(nullptr, tb, keys_in, KA, tags_in, VB, nw, shift, kbits, st));
     if ((rc = e->tmp.ensure(tb))) return rc;
-    KSP_HIP(hipEventRecord(e->ev[4], st));
+    if (e->time_sort) KSP_HIP(hipEventRecord(e->ev[4], st));
     KSP_HIP(rocprim::radix_sort_pairs(e->tmp.p, tb, keys_in, KA, tags_in, VB, nw, shift, kbits, st));
-    KSP_HIP(hipEventRecord(e->ev[5], st));
+    if (e->time_sort) KSP_HIP(hipEventRecord(e->ev[5], st));
     e->sort_entries = nw;
     e->sort_bits = kbits - shift;
     e->part_kind = 1;
@@ -1327,7 +1381,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     }   // phase != 2
     Stage1<V> s1{e, st, phase, n, N, nb, KA, VA, VB, scal, blk_raw, blk_pos, rank1, crank, label, iota, labs, order, newidx, sbound,
                  sorted_src, blk_src, bbits, reorder, hand_zeroed, m};
-    if (reorder && (rc = stage1_source_order(s1))) return rc;
+    if (reorder && !order_queued && (rc = stage1_source_order(s1))) return rc;
     if (m == 0) return KSP_OK;
     e->have_rank_pairs = false;
     e->have_dwork = false;
@@ -1372,7 +1426,7 @@ static int stage_block_tables(ksp_engine* e, hipStream_t st) {
 
 // Last step of stage 1 (single build and assemble alike): the bitmap of block pairs that share a
 // key and the pair-update count of every diagonal tile; finish_build turns them into the work list.
-static int launch_sched_kernels(ksp_engine* e, hipStream_t st, const bool with_tables) {
+static int launch_sched_kernels(ksp_engine* e, hipStream_t st, const bool with_tables, const bool signal) {
     e->have_bits = false;
     e->sched_stream = st;
     const u32 nb = e->nb;
@@ -1465,7 +1519,16 @@ static int launch_sched_kernels(ksp_engine* e, hipStream_t st, const bool with_t
         copy_add(c, e->dwork.p, e->h_stage, ((size_t)nb + 2) * 8);
         if (!direct) copy_add(c, e->tbits.p, e->h_stage + ((size_t)nb + 2) * 8, bit_words * 4);
         if (with_tables && (rc = block_table_regions(e, c))) return rc;   // (the per-block maxima and list offsets ride along)
-        if (direct) hipLaunchKernelGGL(k_pack_flags_out, dim3(grid_for(T, 256)), dim3(256), 0, st, flags, T, reinterpret_cast<u32*>(e->h_stage + ((size_t)nb + 2) * 8), c);
+        e->sched_signalled = false;
+        if (direct && signal) {   // (the last workgroup signals: no event record behind the launch)
+            if ((rc = e->ticket.ensure(64))) return rc;
+            if (!e->ticket_zeroed) { KSP_HIP(hipMemsetAsync(e->ticket.p, 0, 64, st)); e->ticket_zeroed = true; }
+            e->sched_seq += 1;
+            hipLaunchKernelGGL(k_pack_flags_out, dim3(grid_for(T, 256)), dim3(256), 0, st, flags, T, reinterpret_cast<u32*>(e->h_stage + ((size_t)nb + 2) * 8), c,
+                               e->ticket.as<u32>(), reinterpret_cast<unsigned long long*>(e->h_count + 7), e->sched_seq);
+            e->sched_signalled = true;
+        } else if (direct) hipLaunchKernelGGL(k_pack_flags_out, dim3(grid_for(T, 256)), dim3(256), 0, st, flags, T, reinterpret_cast<u32*>(e->h_stage + ((size_t)nb + 2) * 8), c,
+                                              (u32*)nullptr, (unsigned long long*)nullptr, 0ull);
         else hipLaunchKernelGGL(k_copy_regions, dim3(64), dim3(256), 0, st, c);
     }
     KSP_HIP(hipGetLastError());
@@ -1502,7 +1565,9 @@ int ksp_engine_create(int device, ksp_engine** out) {
     ksp_engine* e = new ksp_engine();
     e->device = device;
     hipError_t err = hipHostMalloc((void**)&e->h_count, 64);
+    if (err == hipSuccess) std::memset(e->h_count, 0, 64);   // ([7]: the sequence number of the early work list's copy-out)
     if (err == hipSuccess) err = hipHostMalloc((void**)&e->h_scal, 128);
+    if (err == hipSuccess) std::memset(e->h_scal, 0, 128);   // ([15]: the sequence number of k_readback)
     for (int i = 0; i < 6 && err == hipSuccess; ++i) err = hipEventCreate(&e->ev[i]);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_join_done);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_sched, hipEventDisableTiming);
@@ -1521,7 +1586,7 @@ void ksp_engine_destroy(ksp_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     ksp::Buf* bufs[] = {&e->d_off, &e->KA, &e->KB, &e->VA, &e->VB, &e->R1, &e->FK, &e->FT, &e->asm_small, &e->tmp, &e->bkeys, &e->info,
-                        &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act,
+                        &e->bw, &e->mm, &e->blk_raw, &e->blk_pos, &e->blk_max, &e->part, &e->scalars, &e->count, &e->tailbuf, &e->smap, &e->tbits, &e->dwork, &e->d_act, &e->ticket,
                         &e->d_wg, &e->gp, &e->gm, &e->ms_hist, &e->pmask, &e->crank, &e->PK, &e->PT, &e->PD, &e->parena, &e->PK2, &e->PT2, &e->PD2, &e->seg_tbl, &e->seg_grp, &e->seg_chk, &e->biglist, &e->mcnt, &e->moff, &e->mt0, &e->mt1,
                         &e->mr0, &e->mr1, &e->mstart, &e->stage[0], &e->stage[1]};
     for (auto* b : bufs) b->release();
@@ -1843,10 +1908,21 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     // (polling the event instead of a blocking wait: the join cannot be cut into shares before the build's tables have
     //  landed, and waking a blocked host thread is tens of microseconds of device idle time per step)
     {
+        if (e->sched_early && e->sched_signalled) {   // (the copy-out's last workgroup wrote the number: no event in the stream)
+            volatile unsigned long long* f = reinterpret_cast<volatile unsigned long long*>(e->h_count + 7);
+            for (unsigned long long spins = 1; *f != e->sched_seq; ++spins) {
+                if ((spins & 0xFFFFF) == 0) {   // (now and then: is the stream still alive?)
+                    const hipError_t q = hipStreamQuery(st);
+                    if (q == hipSuccess && *f != e->sched_seq) KSP_HIP(hipErrorUnknown);
+                    if (q != hipErrorNotReady && q != hipSuccess) KSP_HIP(q);
+                }
+            }
+        } else {
         const hipEvent_t landed = e->sched_early ? e->ev_sched : e->ev[1];   // (early work list: the placement pass is still running)
         hipError_t qe;
         while ((qe = hipEventQuery(landed)) == hipErrorNotReady) {}
         KSP_HIP(qe);
+        }
     }
     if (e->sched_early) {
         e->build_ms_pending = true;   // (read off the events by whoever asks first: ksp_engine_get_stats, the join's wait, the next build)
@@ -1862,7 +1938,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     e->st.partition_kind = e->sort_entries ? e->part_kind : 0;
     e->st.partition_fallback = e->part_fail;
     e->st.stage1_kind = e->fused_used;
-    if (e->sort_entries) KSP_HIP(hipEventElapsedTime(&e->st.ms_sort, e->ev[4], e->ev[5]));
+    if (e->sort_entries && e->time_sort) KSP_HIP(hipEventElapsedTime(&e->st.ms_sort, e->ev[4], e->ev[5]));
     return KSP_OK;
 }
 
@@ -2580,8 +2656,9 @@ int ksp_engine_step_launch(ksp_engine* e, const uint64_t* d_keys, const uint32_t
     const bool had_join = e && e->join_pending;
     const u64 had_cap = e ? e->join_cap : 0;
     if (e) e->early_ok = true;   // (the join follows at once, on the same stream: the work list may leave the build early)
+    if (e) e->time_sort = e->profiling;   // (no events around the partition: st.ms_sort stays 0 unless phases are being timed)
     int rc = ksp_engine_build_blocks(e, d_keys, d_weights, h_offsets, n_sources, key_bits, stream);
-    if (e) e->early_ok = false;
+    if (e) { e->early_ok = false; e->time_sort = true; }
     if (rc) return rc;
     if (had_join) {   // the join launched before this build ran in front of it on the stream: its count is there
         e->join_pending = true;
