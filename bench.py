@@ -538,8 +538,14 @@ def main():
                     acc[name] = acc.get(name, 0.0) + ms
                 joins += eng.stats()["ms_join"]
             eng.set_profiling(False)
-            if ms_part == 0.0 and "partition" in acc:   # (the timed steps carry no events around the partition: an event record is a
-                ms_part = acc["partition"] / args.profile_steps   #  ~6 us bubble in the stream; the phase pass has them)
+            # (the timed steps carry no timing events — an event record is a ~6 us bubble in the stream, ksp_engine_step_launch
+            #  records none unless phases are being timed: the split of a step into build / partition / join comes from this pass)
+            if ms_part == 0.0 and "partition" in acc:
+                ms_part = acc["partition"] / args.profile_steps
+            if ms_build == 0.0 and acc:
+                ms_build = sum(acc.values()) / args.profile_steps
+            if ms_join == 0.0 and joins:
+                ms_join = joins / args.profile_steps
             kept = None
             # bytes each group has to move per step; None where no simple model applies
             kind = stats.get("partition_kind")

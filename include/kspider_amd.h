@@ -130,7 +130,11 @@ int ksp_engine_join_wait(ksp_engine* e, uint64_t* h_count);
  * A join launched on this engine before the call (the previous step's) is collected on the way — it ran in front of
  * this build on the stream: *prev_count / *prev_status are what ksp_engine_join_wait would have returned for it,
  * *prev_ms_join (may be NULL) its kernel time.
- * Collect the join launched here with ksp_engine_join_wait, or with the next ksp_engine_step_launch.             */
+ * Collect the join launched here with ksp_engine_join_wait, or with the next ksp_engine_step_launch.
+ * A step launched this way puts NO timing events into the stream (an event record is a ~6 us bubble between two
+ * kernels; a step had eleven): ksp_stats.ms_build / ms_sort / ms_join and *prev_ms_join of such a step read 0 unless
+ * ksp_engine_set_profiling(e, 1) is on.  The host learns of the read-backs, of the work list's inputs and of the
+ * join's count through sequence numbers in pinned memory that it polls.                                              */
 int ksp_engine_step_launch(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d_weights, const uint64_t* h_offsets,
                            uint32_t n_sources, int key_bits, uint32_t part, uint32_t nparts, ksp_edge* d_edges,
                            uint64_t capacity, uint64_t range[2], uint64_t* bound, uint64_t* prev_count, int* prev_status,

@@ -197,6 +197,10 @@ struct ksp_engine {
     u64 h_scal_words = 0, h_scal_keys = 0;   // list words / distinct shared keys of the lists being finished
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // build, join, first radix sort
     bool time_sort = true;        // events around the partition / first sort (st.ms_sort): an event record is a ~6 us bubble in the stream
+    bool lean = false;            // ksp_engine_step_launch without profiling: no timing events at all (st.ms_build / ms_join / ms_sort stay 0),
+                                  // the join's count arrives with a sequence number the wait polls (h_count[6]) instead of ev_join_done
+    bool join_flag = false;       // the pending join signals through that number
+    unsigned long long join_seq = 0;
     hipEvent_t ev_join_done = nullptr;   // behind the count copy of the last ksp_engine_join_launch
     // early work list (ksp_engine_step_launch): the tile flags and block tables leave for the host BEHIND the histogram of
     // the stable split and IN FRONT of its placement pass — the host cuts the join's shares while k_ms_place / k_cidx run,
@@ -1863,7 +1867,7 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
     int rc;
     if ((rc = e->d_off.ensure(((size_t)n_sources + 1) * 8))) return rc;
     KSP_HIP(resolve_build_ms(e));   // (the previous build's time, before its events are recorded again)
-    KSP_HIP(hipEventRecord(e->ev[0], st));
+    if (!e->lean) KSP_HIP(hipEventRecord(e->ev[0], st));
     if (!same_offsets) {   // (the engine's own copy is the source: the caller's array may go away before the copy has run)
         KSP_HIP(hipMemcpyAsync(e->d_off.p, e->h_off.data(), ((size_t)n_sources + 1) * 8, hipMemcpyHostToDevice, st));
         e->d_off_sketch = true;
@@ -1904,11 +1908,12 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
         if ((rc = launch_sched_kernels(e, st, true))) return rc;
         if (!e->blk_staged && (rc = stage_block_tables(e, st))) return rc;
     }
-    KSP_HIP(hipEventRecord(e->ev[1], st));
+    const bool flagged = e->sched_early && e->sched_signalled;
+    if (!(e->lean && flagged)) KSP_HIP(hipEventRecord(e->ev[1], st));   // (lean + signalled: nobody looks at the event)
     // (polling the event instead of a blocking wait: the join cannot be cut into shares before the build's tables have
     //  landed, and waking a blocked host thread is tens of microseconds of device idle time per step)
     {
-        if (e->sched_early && e->sched_signalled) {   // (the copy-out's last workgroup wrote the number: no event in the stream)
+        if (flagged) {   // (the copy-out's last workgroup wrote the number: no event in the stream)
             volatile unsigned long long* f = reinterpret_cast<volatile unsigned long long*>(e->h_count + 7);
             for (unsigned long long spins = 1; *f != e->sched_seq; ++spins) {
                 if ((spins & 0xFFFFF) == 0) {   // (now and then: is the stream still alive?)
@@ -1924,7 +1929,9 @@ static int build_common(ksp_engine* e, const uint64_t* d_keys, const uint32_t* d
         KSP_HIP(qe);
         }
     }
-    if (e->sched_early) {
+    if (e->lean) {
+        e->st.ms_build = 0;           // (no events were recorded)
+    } else if (e->sched_early) {
         e->build_ms_pending = true;   // (read off the events by whoever asks first: ksp_engine_get_stats, the join's wait, the next build)
         e->st.ms_build = 0;
     } else {
@@ -2340,7 +2347,7 @@ int ksp_engine_join_launch(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end
     if (const char* dbg = std::getenv("KSP_DEBUG_ABLATE")) a.dbg = (u32)std::atoi(dbg);
     ZeroList zj{};
     zero_add(zj, a.out_count, 8);
-    KSP_HIP(hipEventRecord(e->ev[2], st));
+    if (!e->lean) KSP_HIP(hipEventRecord(e->ev[2], st));
     dim3 block(JW * 64);
     a.blk_max = e->blk_max.as<u32>();
     a.inv = e->smap.as<u32>() + 3 * smap_stride(e);
@@ -2475,9 +2482,18 @@ int ksp_engine_join_launch(ksp_engine* e, uint64_t tile_begin, uint64_t tile_end
     }
     KSP_HIP(hipGetLastError());
     }   // launch chunks
-    KSP_HIP(hipEventRecord(e->ev[3], st));
-    KSP_HIP(hipMemcpyAsync(e->h_count, a.out_count, 8, hipMemcpyDeviceToHost, st));
-    KSP_HIP(hipEventRecord(e->ev_join_done, st));
+    e->join_flag = false;
+    if (e->lean) {   // the count and a sequence number behind it, by a kernel of ours: no event in the stream
+        e->join_seq += 1;
+        e->join_flag = true;
+        e->rb_stream = st;
+        hipLaunchKernelGGL(k_readback, dim3(1), dim3(64), 0, st, reinterpret_cast<const u64*>(a.out_count), reinterpret_cast<u64*>(e->h_count), 1u,
+                           e->h_count + 6, e->join_seq);
+    } else {
+        KSP_HIP(hipEventRecord(e->ev[3], st));
+        KSP_HIP(hipMemcpyAsync(e->h_count, a.out_count, 8, hipMemcpyDeviceToHost, st));
+        KSP_HIP(hipEventRecord(e->ev_join_done, st));
+    }
     // what ksp_engine_join_wait reports besides the count: known now (a build may start on this engine before the wait)
     e->jst.last_tiles = tile_end - tile_begin;
     e->jst.last_active_tiles = e->sched_on ? (u64)(act1 - act0) : tile_end - tile_begin;
@@ -2513,9 +2529,22 @@ int ksp_engine_join_wait(ksp_engine* e, uint64_t* h_count) {
     if (!e->join_pending) return KSP_OK;   // (nothing was launched: no tile in range, or no shared key at all)
     e->join_pending = false;
     KSP_HIP(hipSetDevice(e->device));
-    KSP_HIP(hipEventSynchronize(e->ev_join_done));
-    KSP_HIP(hipEventElapsedTime(&e->st.ms_join, e->ev[2], e->ev[3]));
-    *h_count = *e->h_count;
+    if (e->join_flag) {
+        e->join_flag = false;
+        volatile unsigned long long* f = reinterpret_cast<volatile unsigned long long*>(e->h_count + 6);
+        for (unsigned long long spins = 1; *f != e->join_seq; ++spins) {
+            if ((spins & 0xFFFFF) == 0) {   // (now and then: is the stream still alive?)
+                const hipError_t q = hipStreamQuery(e->rb_stream);
+                if (q == hipSuccess && *f != e->join_seq) KSP_HIP(hipErrorUnknown);
+                if (q != hipErrorNotReady && q != hipSuccess) KSP_HIP(q);
+            }
+        }
+        e->st.ms_join = 0;
+    } else {
+        KSP_HIP(hipEventSynchronize(e->ev_join_done));
+        KSP_HIP(hipEventElapsedTime(&e->st.ms_join, e->ev[2], e->ev[3]));
+    }
+    *h_count = *reinterpret_cast<volatile unsigned long long*>(e->h_count);
     e->st.last_tiles = e->jst.last_tiles;
     e->st.last_active_tiles = e->jst.last_active_tiles;
     e->st.last_pairs = e->jst.last_pairs;
@@ -2656,10 +2685,11 @@ int ksp_engine_step_launch(ksp_engine* e, const uint64_t* d_keys, const uint32_t
     const bool had_join = e && e->join_pending;
     const u64 had_cap = e ? e->join_cap : 0;
     if (e) e->early_ok = true;   // (the join follows at once, on the same stream: the work list may leave the build early)
-    if (e) e->time_sort = e->profiling;   // (no events around the partition: st.ms_sort stays 0 unless phases are being timed)
+    const bool lean = e && !e->profiling && !std::getenv("KSP_DEBUG_STEP_EVENTS");   // (no timing events in the stream: each is a ~6 us bubble)
+    if (e) { e->time_sort = !lean; e->lean = lean; }
     int rc = ksp_engine_build_blocks(e, d_keys, d_weights, h_offsets, n_sources, key_bits, stream);
     if (e) { e->early_ok = false; e->time_sort = true; }
-    if (rc) return rc;
+    if (rc) { if (e) e->lean = false; return rc; }
     if (had_join) {   // the join launched before this build ran in front of it on the stream: its count is there
         e->join_pending = true;
         e->join_cap = had_cap;
@@ -2667,11 +2697,13 @@ int ksp_engine_step_launch(ksp_engine* e, const uint64_t* d_keys, const uint32_t
         if (prev_ms_join) *prev_ms_join = e->st.ms_join;
     }
     std::vector<u64> cuts((size_t)nparts + 1);
-    if ((rc = ksp_engine_balanced_cuts(e, nparts, cuts.data()))) return rc;
+    if ((rc = ksp_engine_balanced_cuts(e, nparts, cuts.data()))) { e->lean = false; return rc; }
     range[0] = cuts[part]; range[1] = cuts[(size_t)part + 1];
     *bound = ksp_engine_edge_bound(e, range[0], range[1]);
-    if (*bound + 1 > capacity) { set_error("step_launch: the edge bound exceeds the buffer (nothing launched)"); return KSP_E_OVERFLOW; }
-    return ksp_engine_join_launch(e, range[0], range[1], d_edges, capacity, stream);
+    if (*bound + 1 > capacity) { e->lean = false; set_error("step_launch: the edge bound exceeds the buffer (nothing launched)"); return KSP_E_OVERFLOW; }
+    rc = ksp_engine_join_launch(e, range[0], range[1], d_edges, capacity, stream);
+    e->lean = false;
+    return rc;
 }
 
 int ksp_engine_set_profiling(ksp_engine* e, int on) {
