@@ -516,6 +516,7 @@ def main():
     ms_join = stats["ms_join"] / steps
     ms_build = stats["ms_build"] / steps
     ms_part = stats["ms_sort"] / steps
+    stage_from_phase_pass = False
 
     if rank == 0:
         E = int(stats["edges"])
@@ -544,6 +545,7 @@ def main():
                 ms_part = acc["partition"] / args.profile_steps
             if ms_build == 0.0 and acc:
                 ms_build = sum(acc.values()) / args.profile_steps
+                stage_from_phase_pass = True
             if ms_join == 0.0 and joins:
                 ms_join = joins / args.profile_steps
             kept = None
@@ -612,8 +614,12 @@ def main():
                                "x_hbm_peak": naive / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS / world,
                                "note": "SURVEY 8(d) per-pair bytes 8(n_a+n_b)+4 over all pairs / step time: what a "
                                        "pair-by-pair merge would have to stream; not a roofline of this engine"},
-            "stage_ms": {"build_blocks": ms_build, "of which partition": ms_part, "join": ms_join,
-                         "other (gather, D2H, sync, host)": ms_step - ms_build - ms_join},
+            "stage_ms": ({"build_blocks": ms_build, "of which partition": ms_part, "join": ms_join,
+                          "measured_in": "the phase pass after the timed steps (one timing event per phase start: ~0.05 ms of "
+                                         "bubbles per step that the timed steps, which carry no events, do not have)"}
+                         if stage_from_phase_pass else
+                         {"build_blocks": ms_build, "of which partition": ms_part, "join": ms_join,
+                          "other (gather, D2H, sync, host)": ms_step - ms_build - ms_join}),
         }
         if world == 1 and args.cpu_sample > 0:
             try:

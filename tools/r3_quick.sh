@@ -8,6 +8,6 @@ timeout -k 10 200 python bench.py --steps 20 --warmup 5 --cpu-sample 0 --other-c
 python - <<EOF
 import json
 d=json.load(open("$O/bench.json"))
-print("ms_per_step", round(d["ms_per_step"],4), {k: round(v,4) for k,v in d["stage_ms"].items()}, "edges", d["config"]["nonzero_pairs"], "chk", d["config"]["checksum"])
+print("ms_per_step", round(d["ms_per_step"],4), {k: round(v,4) for k,v in d["stage_ms"].items() if isinstance(v,float)}, "edges", d["config"]["nonzero_pairs"], "chk", d["config"]["checksum"])
 for g in d["roofline"]["groups"]: print("  ", g["group"], round(g["ms"],4))
 EOF
