@@ -266,14 +266,23 @@ __global__ __launch_bounds__(1024) void k_pack_blocks(const u32* __restrict__ la
     u32 last = 0;
     for (u32 p = p0; p < p1; ++p)
         if (s_d[p]) last = p + 1;
-    s_head[tid] = last;
-    __syncthreads();
-    for (u32 o = 1; o < 1024; o <<= 1) {   // inclusive max-scan (heads ascend with the position)
-        const u32 v = tid >= o ? s_head[tid - o] : 0u;
+    // inclusive max-scan over the threads (heads ascend with the position): inside a wave on the vector unit, the sixteen
+    // wave maxima through LDS — two barriers instead of the twenty of a shared-memory scan
+    {
+        u32 x = last;
+        x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));   // row_shr:1
+        x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));   // row_shr:2
+        x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));   // row_shr:4
+        x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));   // row_shr:8
+        x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+        x = max(x, (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+        if ((tid & 63) == 63) s_head[tid >> 6] = x;   // (s_head[0..15]: the waves' maxima)
         __syncthreads();
-        s_head[tid] = max(s_head[tid], v);
+        for (u32 w = 0; w < (tid >> 6); ++w) x = max(x, s_head[w]);
         __syncthreads();
+        s_head[tid] = x;
     }
+    __syncthreads();
     {
         u32 head = tid ? s_head[tid - 1] : 0u;   // (+ 1; position 0 is always a head, so 0 never survives the first store)
         for (u32 p = p0; p < p1; ++p) {
