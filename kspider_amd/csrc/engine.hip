@@ -345,6 +345,13 @@ __global__ void k_readback(const u64* __restrict__ src, u64* __restrict__ dst_ho
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// ... or riding along with the next kernel (k_label, k_move_groups): the same words, no dispatch of their own
+static inline Rider ride_readback(ksp_engine* e, hipStream_t st, const u64* src, u64* dst_host, const u32 words) {
+    e->rb_seq += 1;
+    e->rb_flag = true;
+    e->rb_stream = st;
+    return Rider{src, dst_host, reinterpret_cast<unsigned long long*>(e->h_scal + 15), e->rb_seq, words};
+}
 static inline void launch_readback(ksp_engine* e, hipStream_t st, const u64* src, u64* dst_host, const u32 words) {
     e->rb_seq += 1;
     e->rb_flag = true;
@@ -511,7 +518,7 @@ static int stage1_lists_by_key(const Stage1<V>& c, bool& done) {
         }
         // the number of groups sizes the sort of the groups and what follows; the records themselves are packed (k_move_groups)
         // while the host waits for it: their arrays take the bound K <= m
-        launch_readback(e, st, scal + 1, e->h_scal + 1, 11);   // [1] groups ... [11] overflow
+        const Rider rb = ride_readback(e, st, scal + 1, e->h_scal + 1, 11);   // [1] groups ... [11] overflow: with k_move_groups
         const u64 Kcap = m;
         if ((rc = e->gp.ensure((Kcap + 4) * 20))) return rc;
         e->gp_stride = Kcap + 4;
@@ -531,7 +538,7 @@ static int stage1_lists_by_key(const Stage1<V>& c, bool& done) {
             if (const char* mc = std::getenv("KSP_DEBUG_MOVE_GRID")) mg_cap = (u32)std::max(1, std::atoi(mc));   // (timing experiments)
             hipLaunchKernelGGL(k_move_groups, dim3(std::min<u32>(grid_for(U, bs), mg_cap)), dim3(bs), 0, st, gsum, goff, firstp,
                                blk0, info0, mask0, tmp_blk, tmp_info, tmp_mask, rec_blk, rec_val, rec_rank, e->mm.as<uint4>(),
-                               U, work, nb, d_kovf);
+                               U, work, nb, d_kovf, rb);
         }
         KSP_HIP(wait_readback(e));
         if ((u32)e->h_scal[11]) {
@@ -727,7 +734,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
     u32 label_max = std::max<u32>(256, N / 16);   // holders above which a key is ignored by the label pass
     if (const char* lm = std::getenv("KSP_DEBUG_LABEL_MAX")) label_max = (u32)std::max(1, std::atoi(lm));
     // the label pass over the kept keys (first[] = where each key's entries start); KB is free whenever it runs
-    auto run_label = [&](const u32* firstp, const u32 n_keys, const u64 kept, const u64* scal_dev = nullptr) {
+    auto run_label = [&](const u32* firstp, const u32 n_keys, const u64 kept, const u64* scal_dev = nullptr, const Rider rider = Rider{nullptr, nullptr, nullptr, 0, 0}) {
         const u32 skip = label_sampling(e, kept);
         // labels on memory lines of their own while they are lowered — for source sets whose labels would otherwise share a
         // few hundred lines (10 000 sources: 98 -> 39 us).  A large set spreads its atomics by itself, and 128 bytes per
@@ -739,7 +746,7 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         u32* lab = ls ? (u32*)e->KB.p : label;
         if (ls) hipLaunchKernelGGL(k_label_spread, dim3(grid_for(N, bs)), dim3(bs), 0, st, lab, ls, N);
         hipLaunchKernelGGL((k_label<V>), dim3(grid_for(n_keys / (skip + 1) + 1, bs)), dim3(bs), 0, st, VA, firstp, lab, ls,
-                           skip, label_max, n_keys, scal_dev);
+                           skip, label_max, n_keys, scal_dev, rider);
         if (ls) hipLaunchKernelGGL(k_label_gather, dim3(grid_for(N, bs)), dim3(bs), 0, st, lab, ls, label, N);
     };
     bool hand_zeroed = false;   // this build began with the hand-written partition's zeroing launch (the whole scalar block)
@@ -1298,11 +1305,11 @@ static int build_impl(ksp_engine* e, const u64* d_keys, const u32* d_w, hipStrea
         // [0] max key, [2] keys, [6] entries, [9] / [14] overflow.  The kept-entry count sizes every later pass — but the label
         // pass can be queued without it (its key count comes from the device, its sampling rate from the kept fraction of
         // the engine's previous build), so the device works on while the host waits for the words
-        if (reorder) launch_readback(e, st, scal, e->h_scal, 15);
-        else KSP_HIP(hipMemcpyAsync(e->h_scal, scal, 120, hipMemcpyDeviceToHost, st));
+        if (!reorder) KSP_HIP(hipMemcpyAsync(e->h_scal, scal, 120, hipMemcpyDeviceToHost, st));
         if (reorder) {
             phase_mark(e, st, "source labels + order");
-            run_label(first, (u32)std::min<u64>(nw / 2 + 1, 0x7FFFFFFFu), (u64)((double)nw * e->kept_frac), scal);
+            run_label(first, (u32)std::min<u64>(nw / 2 + 1, 0x7FFFFFFFu), (u64)((double)nw * e->kept_frac), scal,
+                      ride_readback(e, st, scal, e->h_scal, 15));   // (the words ride along with k_label)
             labels_queued = true;
             if (phase == 0) {   // (... and neither does the order of the sources need it: sort, block cuts and placement are queued too)
                 const Stage1<V> so{e, st, phase, n, N, nb, KA, VA, VB, scal, blk_raw, blk_pos, rank1, crank, label, iota, labs, order, newidx,

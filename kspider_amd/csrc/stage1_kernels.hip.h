@@ -67,6 +67,23 @@ __device__ inline u64 wave_all_or(const u64 x, const int lane) {
     return (u64)lo | ((u64)hi << 32);
 }
 
+// A read-back that rides along with the next kernel instead of taking a dispatch of its own (~4.5 us each): the first wave
+// of the kernel's first workgroup copies a few words of the scalar block to pinned host memory and writes a sequence
+// number behind them, before it does anything else; the host polls the number (engine.hip: wait_readback).
+struct Rider {
+    const u64* src;
+    u64* dst_host;
+    unsigned long long* flag_host;
+    unsigned long long seq;
+    u32 words;   // 0: nothing rides along
+};
+__device__ inline void rider_run(const Rider& r) {
+    if (r.words && blockIdx.x == 0 && threadIdx.x < 64) {
+        if (threadIdx.x < r.words) __hip_atomic_store(r.dst_host + threadIdx.x, r.src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        if (threadIdx.x == 0) __hip_atomic_store(r.flag_host, r.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 // ------------------------------------------------------------------------------------
 // stage 1 kernels
 // ------------------------------------------------------------------------------------
@@ -150,7 +167,9 @@ __global__ void k_iota4(u32* __restrict__ p0, u32* __restrict__ p1, u32* __restr
 __device__ inline u32 src_of_tag(u32 t) { return (t >> 8) * TB + (t & 0xFFu); }
 template <class V>
 __global__ void k_label(const V* __restrict__ vals, const u32* __restrict__ first, u32* __restrict__ label,
-                        const int lshift, const u32 skip, const u32 max_holders, u32 n_keys, const u64* __restrict__ scal) {
+                        const int lshift, const u32 skip, const u32 max_holders, u32 n_keys, const u64* __restrict__ scal,
+                        const Rider rider) {
+    rider_run(rider);
     // scal != NULL: launched before the host has read the grouping's results back — the key count comes from the
     // device (n_keys is an upper bound) and nothing is touched when the grouping gave up (the build is repeated)
     if (scal) {
@@ -1222,8 +1241,10 @@ __global__ __launch_bounds__(256) void k_move_groups(const u64* __restrict__ gsu
                                                      const uint4* __restrict__ tmp_mask, u32* __restrict__ rec_blk,
                                                      u64* __restrict__ rec_val, u32* __restrict__ rec_rank,
                                                      uint4* __restrict__ bigmask, u32 n_keys,
-                                                     unsigned long long* __restrict__ work, u32 nb, const u32* __restrict__ ovf) {
+                                                     unsigned long long* __restrict__ work, u32 nb, const u32* __restrict__ ovf,
+                                                     const Rider rider) {
     __shared__ unsigned long long s_work[KG_WORK + 1];
+    rider_run(rider);
     if (*ovf) return;   // (queued before the host knew: a key with too many holders — the build sorts the entries by block instead)
     if (work) {
         for (u32 i = threadIdx.x; i <= nb; i += blockDim.x) s_work[i] = 0;
